@@ -1,0 +1,69 @@
+"""Deterministic KITTI-like synthetic sparse-depth frames.
+
+Workload generation for tests and bench.py: 352x1216 f32, 0 = empty, ~4-5 % valid,
+upper ~30 % of the image empty (like a projected velodyne scan), depths 0.5-85 m
+quantised to 1/256 m (KITTI uint16 PNG / 256, reference src/DC_lidar_only/main.cpp:79).
+Counter-based (SplitMix64 keyed by seed,row,col) so any frame can be produced anywhere
+without a stream state; oracle/dcmt_oracle.c:dcmt_oracle_synth_frame is the same
+function in C and tests check the two agree bit for bit.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def synth_frame(rows: int = 352, cols: int = 1216, seed: int = 0) -> np.ndarray:
+    key = _splitmix64(np.array([seed], dtype=np.uint64))[0]
+    r = np.arange(rows, dtype=np.int64)
+    re = (r * 352) // rows
+    t = np.clip((re - 110) / 60.0, 0.0, 1.5)
+    thr = np.floor(t * 0.05 * 16777216.0).astype(np.uint32)
+    den = np.maximum(re - 172, 2)
+    base = np.clip((1.65 * 721.5) / den, 2.0, 85.0)
+    rc = (r.astype(np.uint64)[:, None] << np.uint64(32)) | np.arange(cols, dtype=np.uint64)[None, :]
+    h = _splitmix64(key ^ rc)
+    u1 = ((h >> np.uint64(40)) & np.uint64(0xFFFFFF)).astype(np.uint32)
+    u2 = ((h >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(np.float64)
+    f = 0.6 + 0.8 * (u2 / 16777216.0)
+    d = np.clip(base[:, None] * f, 0.5, 85.0)
+    q = np.floor(d * 256.0 + 0.5)
+    v = (q / 256.0).astype(np.float32)
+    return np.where(u1 < thr[:, None], v, np.float32(0)).astype(np.float32)
+
+
+def synth_batch(n: int, rows: int = 352, cols: int = 1216, seed0: int = 0) -> np.ndarray:
+    """Frames seed0 .. seed0+n-1, shape [n][rows][cols]."""
+    out = np.empty((n, rows, cols), dtype=np.float32)
+    for i in range(n):
+        out[i] = synth_frame(rows, cols, seed0 + i)
+    return out
+
+
+def synth_labels(rows: int = 352, cols: int = 1216, n_target: int = 1200, seed: int = 0) -> tuple[np.ndarray, int]:
+    """SLIC-like label plane: a jittered grid of ~n_target cells (step = sqrt(W*H/n), as
+    reference src/DC_lidar_camera/main_lc.cpp:188-197), int32[rows][cols], plus n_labels.
+    Cell borders are perturbed per pixel so labels interleave like real superpixels."""
+    step = max(2, int(np.sqrt(rows * cols / float(n_target))))
+    gy, gx = (rows + step - 1) // step, (cols + step - 1) // step
+    key = _splitmix64(np.array([seed ^ 0x5EED], dtype=np.uint64))[0]
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    c = np.arange(cols, dtype=np.uint64)[None, :]
+    h = _splitmix64(key ^ ((r << np.uint64(32)) | c))
+    jr = ((h >> np.uint64(8)) % np.uint64(5)).astype(np.int64) - 2
+    jc = ((h >> np.uint64(24)) % np.uint64(5)).astype(np.int64) - 2
+    rr = np.clip(np.arange(rows, dtype=np.int64)[:, None] + jr, 0, rows - 1)
+    cc = np.clip(np.arange(cols, dtype=np.int64)[None, :] + jc, 0, cols - 1)
+    lab = (rr // step) * gx + (cc // step)
+    # a sprinkle of unassigned pixels (-1), as SLIC leaves some
+    lab = np.where((h >> np.uint64(50)) % np.uint64(997) == 0, -1, lab)
+    return lab.astype(np.int32), int(gy * gx)

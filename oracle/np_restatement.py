@@ -1,0 +1,208 @@
+"""Second, independently written restatement of the reference cascade, in numpy.
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED (OpenCV absent, the reference
+ships no fixtures).  This file exists to (a) cross-check oracle/dcmt_oracle.c -- two
+restatements written in different styles (whole-array shifted slices here, scalar loops
+there) agreeing bit for bit is the best substitute for executing OpenCV that this image
+allows -- and (b) generate the golden vectors in tests/golden/ (tests/golden/make_golden.py).
+
+Follows /root/reference/src/DC_lidar_only/img_completion.cpp:17-204 and
+src/DC_lidar_camera/img_completion_lc.cpp:34-203.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+FLT_MAX = np.finfo(np.float32).max
+
+# LO/img_completion.cpp:71-77 -- int d[5][5] viewed as 25 bytes (little endian host)
+K0_AS_COMPILED = np.frombuffer(
+    np.array([0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 0, 0, 0, 1, 0, 0],
+             dtype="<i4").tobytes()[:25], dtype=np.uint8).reshape(5, 5).copy()
+K0_DIAMOND = np.array([0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 0, 0, 0, 1, 0, 0],
+                      dtype=np.uint8).reshape(5, 5)
+
+
+def _valid(x):   # `depth > 0.1`: float promoted to double against the double literal
+    return x.astype(np.float64) > 0.1
+
+
+def _hole(x):    # `depth < 0.1`
+    return x.astype(np.float64) < 0.1
+
+
+def invert(x, max_depth=F32(100.0)):
+    """LO :55-67 / :191-202."""
+    return np.where(_valid(x), F32(max_depth) - x, x).astype(F32)
+
+
+def _shifted(x, dr, dc, fill):
+    """y[r,c] = x[r+dr, c+dc], `fill` outside the image."""
+    R, C = x.shape
+    y = np.full_like(x, fill)
+    rs0, rs1 = max(0, dr), min(R, R + dr)
+    cs0, cs1 = max(0, dc), min(C, C + dc)
+    if rs0 < rs1 and cs0 < cs1:
+        y[rs0 - dr:rs1 - dr, cs0 - dc:cs1 - dc] = x[rs0:rs1, cs0:cs1]
+    return y
+
+
+def dilate(x, kernel):
+    """cv::dilate, anchor centre, element not reflected, border -FLT_MAX (LO :80,:85,:90,:134)."""
+    kh, kw = kernel.shape
+    out = np.full_like(x, -FLT_MAX)
+    for kr in range(kh):
+        for kc in range(kw):
+            if kernel[kr, kc]:
+                out = np.maximum(out, _shifted(x, kr - kh // 2, kc - kw // 2, -FLT_MAX))
+    return out
+
+
+def erode(x, kernel):
+    """cv::erode, border +FLT_MAX (second half of MORPH_CLOSE, LO :85)."""
+    kh, kw = kernel.shape
+    out = np.full_like(x, FLT_MAX)
+    for kr in range(kh):
+        for kc in range(kw):
+            if kernel[kr, kc]:
+                out = np.minimum(out, _shifted(x, kr - kh // 2, kc - kw // 2, FLT_MAX))
+    return out
+
+
+def _ones(k):
+    return np.ones((k, k), dtype=np.uint8)
+
+
+def dilate_rect_fast(x, k):
+    """Same as dilate(x, ones(k,k)) via two 1-D passes (exactness of max)."""
+    return dilate(dilate(x, np.ones((1, k), np.uint8)), np.ones((k, 1), np.uint8))
+
+
+def fill(x, k):
+    """s = dilate(clone(x), ones(k,k)); x = x<0.1 ? s : x (LO :88-100, :131-144)."""
+    s = dilate_rect_fast(x, k)
+    h = _hole(x)
+    return np.where(h, s, x).astype(F32), int(h.sum())
+
+
+def extend_columns(x):
+    """LO :103-129."""
+    x = x.copy()
+    R, C = x.shape
+    v = _valid(x)
+    for j in range(C):
+        idx = np.flatnonzero(v[:, j])
+        if idx.size == 0:
+            # first loop writes -1 from row 0, second overwrites rows R-1..0 with 100
+            x[:, j] = F32(100.0)
+            continue
+        top, bot = idx[0], idx[-1]
+        bv, tv = x[bot, j], x[top, j]
+        x[bot:, j] = bv
+        x[:top + 1, j] = tv
+    return x
+
+
+def median5(x):
+    """cv::medianBlur(x,x,5) on f32: exact median, BORDER_REPLICATE (LO :170)."""
+    R, C = x.shape
+    p = np.pad(x, 2, mode="edge")
+    stack = np.stack([p[r:r + R, c:c + C] for r in range(5) for c in range(5)], axis=0)
+    return np.sort(stack, axis=0)[12].astype(F32)
+
+
+def gaussian5(x):
+    """cv::GaussianBlur(x,x,Size(5,5),0): [1,4,6,4,1]/16, REFLECT_101, f32 (LO :179)."""
+    k0, k1, k2 = F32(0.375), F32(0.25), F32(0.0625)
+    R, C = x.shape
+
+    def pad101(a, axis):
+        n = a.shape[axis]
+        if n == 1:
+            return np.concatenate([a] * 5, axis=axis)
+        idx = np.arange(-2, n + 2)
+        for _ in range(4):
+            idx = np.where(idx < 0, -idx, idx)
+            idx = np.where(idx >= n, 2 * n - 2 - idx, idx)
+        return np.take(a, idx, axis=axis)
+
+    p = pad101(x, 1)
+    t = (p[:, 2:2 + C] * k0).astype(F32)
+    t = (t + ((p[:, 1:1 + C] + p[:, 3:3 + C]).astype(F32) * k1).astype(F32)).astype(F32)
+    t = (t + ((p[:, 0:C] + p[:, 4:4 + C]).astype(F32) * k2).astype(F32)).astype(F32)
+    p = pad101(t, 0)
+    o = (p[2:2 + R] * k0).astype(F32)
+    o = (o + ((p[1:1 + R] + p[3:3 + R]).astype(F32) * k1).astype(F32)).astype(F32)
+    o = (o + ((p[0:R] + p[4:4 + R]).astype(F32) * k2).astype(F32)).astype(F32)
+    return o
+
+
+def _tail(x, stop_after, blur, max_fill_iters, info):
+    x, _ = fill(x, 7)                                   # H5
+    if stop_after <= 5:
+        return x
+    x = extend_columns(x)                               # H6
+    if stop_after <= 6:
+        return x
+    x, n = fill(x, 31)                                  # H7
+    info["holes_after_extend"] = n
+    if stop_after <= 7:
+        return x
+    iters = 0
+    while True:                                         # H8
+        x, n = fill(x, 31)
+        iters += 1
+        if n == 0 or iters >= max_fill_iters:
+            break
+    info["fill_iters"] = iters
+    if stop_after <= 8:
+        return x
+    x = median5(x)                                      # H9
+    if stop_after <= 9:
+        return x
+    if blur == "gaussian":                              # H10
+        g = gaussian5(x)
+        x = np.where(_valid(x), g, x).astype(F32)
+    if stop_after <= 10:
+        return x
+    return invert(x)                                    # H11
+
+
+def img_completion(sparse, k0=K0_AS_COMPILED, blur="gaussian", stop_after=11, max_fill_iters=64,
+                   info=None):
+    info = {} if info is None else info
+    x = invert(np.asarray(sparse, dtype=F32))           # H0, H2
+    if stop_after <= 2:
+        return x
+    x = dilate(x, k0)                                   # H3
+    if stop_after <= 3:
+        return x
+    x = erode(dilate(x, _ones(5)), _ones(5))            # H4
+    if stop_after <= 4:
+        return x
+    return _tail(x, stop_after, blur, max_fill_iters, info)
+
+
+def interpolate_with_superpixels(sparse, labels, n_labels, k0=K0_AS_COMPILED, use_superpixel=1,
+                                 stop_after=11, max_fill_iters=64, info=None):
+    """LC :34-203 (one whole-image pass per label, literally)."""
+    info = {} if info is None else info
+    x = invert(np.asarray(sparse, dtype=F32))
+    if stop_after <= 2:
+        return x
+    if use_superpixel == 0:
+        x = dilate(x, k0)
+        x = erode(dilate(x, _ones(5)), _ones(5))
+    else:
+        labels = np.asarray(labels)
+        for c in range(n_labels):
+            m = labels == c
+            if not m.any():
+                continue
+            region = np.where(m, x, F32(0)).astype(F32)
+            region = erode(dilate(dilate(region, k0), _ones(5)), _ones(5))
+            x = np.where(m, region, x).astype(F32)
+    if stop_after <= 4:
+        return x
+    return _tail(x, stop_after, "gaussian", max_fill_iters, info)

@@ -1,0 +1,122 @@
+"""Generates the golden vectors in this directory.
+
+Run from the repo root:  python tests/golden/make_golden.py
+
+The vectors are produced by oracle/np_restatement.py (the numpy restatement of the
+reference cascade); the C oracle and the HIP path must both reproduce them (bit-exact
+through the median stage; the Gaussian stage bit-exact against these two restatements and
+within 1e-4 of any other conforming OpenCV build).  PARITY UNPINNED: the
+reference ships no fixtures and OpenCV cannot be executed in this image, so these vectors
+pin the restated semantics, not an OpenCV run.  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from depth_completion_mt_amd import synth  # noqa: E402
+from oracle import np_restatement as N  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def adversarial_cases():
+    """Small inputs that force the rare branches."""
+    cases = {}
+    z = np.zeros((24, 40), np.float32)
+    cases["all_empty"] = z.copy()                                   # K1
+    a = z.copy(); a[12, 20] = 10.0
+    cases["single_pixel"] = a                                       # K2 (small version)
+    a = synth.synth_frame(40, 56, 11); a[:, 10:14] = 0; a[:, 55] = 0
+    cases["empty_columns"] = a                                      # K6
+    a = synth.synth_frame(40, 56, 12)
+    a[5, 5] = 99.95; a[6, 7] = 100.0; a[30, 30] = 120.0; a[31, 31] = 99.9
+    cases["near_max_depth"] = a                                     # K7
+    a = z.copy(); a[3, 3] = np.float32(0.1); a[3, 20] = np.nextafter(np.float32(0.1), np.float32(0))
+    a[20, 3] = 0.5; a[20, 30] = 0.100000024
+    cases["threshold"] = a                                          # K4
+    a = synth.synth_frame(40, 56, 13); a[a == 0] = 7.5
+    cases["dense"] = a
+    a = z.copy(); a[0, :] = 20.0; a[-1, :] = 30.0; a[:, 0] = 5.0; a[:, -1] = 6.0
+    cases["border_only"] = a
+    # tall gap: valid bands top and bottom only -> several H8 iterations
+    a = np.zeros((200, 48), np.float32); a[0:2, :] = 40.0; a[198:200, :] = 12.0
+    cases["tall_gap"] = a
+    # never converges within the cap: a wide region whose neighbourhood max stays < 0.1
+    a = np.zeros((120, 120), np.float32); a[:, :] = 120.0   # all > max_depth -> negative
+    a[0, :] = 10.0; a[-1, :] = 10.0
+    cases["negative_region"] = a
+    a = np.float32(3.25) * np.ones((1, 9), np.float32); a[0, 4] = 0
+    cases["one_row"] = a
+    a = np.float32(3.25) * np.ones((9, 1), np.float32); a[4, 0] = 0
+    cases["one_col"] = a
+    cases["tiny_3x4"] = np.array([[0, 5, 0, 0], [0, 0, 0, 9], [1, 0, 0, 0]], np.float32)
+    return cases
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()
+
+
+def main():
+    out = {}
+    # per-stage goldens on a crop
+    x = synth.synth_frame(48, 64, 3)
+    out["crop48x64_in"] = x
+    for st in range(2, 12):
+        out[f"crop48x64_stage{st}"] = N.img_completion(x, stop_after=st)
+    out["crop48x64_diamond"] = N.img_completion(x, k0=N.K0_DIAMOND)
+    out["crop48x64_noblur"] = N.img_completion(x, blur="none")
+    x = synth.synth_frame(33, 70, 7)
+    out["odd33x70_in"] = x
+    out["odd33x70_out"] = N.img_completion(x)
+    out["odd33x70_diamond"] = N.img_completion(x, k0=N.K0_DIAMOND)
+    # adversarial
+    meta = {"adversarial": {}}
+    for name, a in adversarial_cases().items():
+        info = {}
+        out[f"adv_{name}_in"] = a
+        out[f"adv_{name}_out"] = N.img_completion(a, info=info, max_fill_iters=8)
+        meta["adversarial"][name] = info
+    # label-masked variant (LC)
+    x = synth.synth_frame(40, 56, 21)
+    lab, nl = synth.synth_labels(40, 56, 12, 21)
+    out["lc40x56_in"] = x
+    out["lc40x56_labels"] = lab
+    out["lc40x56_stage4"] = N.interpolate_with_superpixels(x, lab, nl, stop_after=4)
+    out["lc40x56_out"] = N.interpolate_with_superpixels(x, lab, nl)
+    out["lc40x56_out_nosp"] = N.interpolate_with_superpixels(x, lab, nl, use_superpixel=0)
+    meta["lc40x56_n_labels"] = nl
+    np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **out)
+
+    # full-size frames: checksums only (inputs come from the generator)
+    full = {}
+    for rows, cols, seed in [(352, 1216, 0), (352, 1216, 1), (375, 1242, 1)]:
+        x = synth.synth_frame(rows, cols, seed)
+        info = {}
+        y9 = N.img_completion(x, stop_after=9, info=info)
+        y = N.img_completion(x)
+        full[f"{rows}x{cols}_seed{seed}"] = {
+            "in_sha256": sha(x), "stage9_sha256": sha(y9), "out_sha256": sha(y),
+            "holes_after_extend": info["holes_after_extend"], "fill_iters": info["fill_iters"],
+            "out_sum_f64": float(y.astype(np.float64).sum()),
+        }
+    lab, nl = synth.synth_labels(352, 1216, 1200, 0)
+    x = synth.synth_frame(352, 1216, 0)
+    y = N.interpolate_with_superpixels(x, lab, nl)
+    full["lc_352x1216_seed0"] = {"labels_sha256": hashlib.sha256(lab.tobytes()).hexdigest(),
+                                 "n_labels": nl, "out_sha256": sha(y)}
+    meta["full"] = full
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
