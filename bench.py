@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the img_completion cascade on device-resident batches.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A step = one pass of the hot path (dcmt_complete_f32_dev, all kernels of the cascade) over
+one device-resident batch of `--batch` synthetic 352x1216 sparse-depth frames per GPU.
+Frames are independent, so ranks shard the frames with NO collective on the data path
+(torch.distributed is used for the barriers and the max-over-ranks of the elapsed time
+only); scaling is weak: every rank processes its own `--batch` frames per step.
+
+Prints ONE JSON line (rank 0).  value = frames/s over all ranks.  roofline.achieved =
+algorithmic bytes (8 B/px: sparse f32 in + dense f32 out, intermediates count zero) per
+step / mean GPU time per step measured with HIP events on the launch stream.
+cpu_baseline = the CPU oracle (a port: OpenCV is not installed, the reference cannot be
+built) on this box's host cores, frame-parallel, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ROWS, COLS = 352, 1216
+BYTES_PER_FRAME = ROWS * COLS * 8           # read 1,712,128 + write 1,712,128
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0               # same guide: measured float4-copy ceiling
+
+
+def cpu_baseline(n_threads: int, budget_s: float = 12.0):
+    """Oracle (kind 'port') on the host cores: bounded sample of the same synthetic frames."""
+    import numpy as np
+    from depth_completion_mt_amd import synth
+    from oracle import oracle as O          # checker/baseline only; never on the product path
+    try:
+        O.lib(native=True)
+        native = True
+    except Exception:
+        native = False
+    one = synth.synth_batch(1, ROWS, COLS, 0)
+    t0 = time.perf_counter()
+    O.img_completion_batch(one, threads=1, native=native)
+    t1 = time.perf_counter() - t0                       # single-thread seconds per frame
+    n = max(n_threads, int(budget_s / max(t1, 1e-3) * n_threads / 2))
+    n = min(n, 8 * n_threads)
+    frames = synth.synth_batch(n, ROWS, COLS, 1000)
+    t0 = time.perf_counter()
+    O.img_completion_batch(frames, threads=n_threads, native=native)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n} synthetic {COLS}x{ROWS} frames, frame-parallel OpenMP over {n_threads} threads, "
+                      f"oracle/dcmt_oracle.c ({'-O3 -march=native' if native else '-O2'}); "
+                      f"OpenCV absent so the reference itself cannot run",
+            "single_thread_frames_per_s": 1.0 / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames per GPU (tiled to --batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch1", action="store_true", help="also time batch=1 streamed launches (configs[1])")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from depth_completion_mt_amd import Context, make_params, synth
+    from depth_completion_mt_amd import _lib as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available() or L.lib().dcmt_device_count() < 1:
+        raise SystemExit("bench.py needs a gfx950 GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    uniq = min(args.unique, B)
+    host = synth.synth_batch(uniq, ROWS, COLS, seed0=rank * 100003)
+    d_uniq = torch.from_numpy(host).cuda()
+    reps = (B + uniq - 1) // uniq
+    d_src = d_uniq.repeat(reps, 1, 1)[:B].contiguous()
+    d_dst = torch.empty_like(d_src)
+    ctx = Context(local_rank, ROWS, COLS, B)
+    params = make_params()                              # the reference's literals; 1 speculative loop application
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.complete_dev(d_src, d_dst, params, stream=stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream
+
+    # every frame must have converged inside the timed configuration (no skipped work)
+    iters, st = ctx.last_fill_iters(B)
+    if st != L.OK:
+        raise SystemExit("a frame needed more hole-closure applications than were enqueued: result invalid")
+
+    if dist is not None:
+        t = torch.tensor([elapsed, gpu_ms_per_step], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, gpu_ms_per_step = float(t[0]), float(t[1])
+
+    extra = {}
+    if args.batch1 and rank == 0:
+        ctx1 = Context(local_rank, ROWS, COLS, 1)
+        n1 = 300
+        for i in range(20):
+            ctx1.complete_dev(d_src[i % B], d_dst[i % B], params, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n1):
+            ctx1.complete_dev(d_src[i % B], d_dst[i % B], params, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        extra["batch1_streamed_frames_per_s"] = n1 / (time.perf_counter() - t1)
+        ctx1.close()
+
+    if rank == 0:
+        frames_total = B * world * args.steps
+        value = frames_total / elapsed
+        achieved = B * BYTES_PER_FRAME / (gpu_ms_per_step * 1e-3) / 1e9      # GB/s per GPU, whole chain
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")       # written by tools/pmc_traffic.py
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "depth frames/sec at 1216x352 (KITTI); achieved HBM GB/s vs peak",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic KITTI-like sparse depth (depth_completion_mt_amd/synth.py), {uniq} distinct frames per GPU tiled to {B}",
+            "config": {"workload": f"DC_lidar_only img_completion, {COLS}x{ROWS} f32, device-resident batch of {B} frames per GPU per step "
+                                   f"(BASELINE configs[4] sharding; configs[1] batch=1 is latency-bound, see --batch1)",
+                       "frames_per_gpu_per_step": B, "rows": ROWS, "cols": COLS, "k0": "as_compiled", "blur": "gaussian",
+                       "sharding": "per-frame, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+                         "gpu_ms_per_step": gpu_ms_per_step, "algorithmic_bytes_per_step": B * BYTES_PER_FRAME,
+                         "kernel": "whole cascade (k_init + k_pre + k_fill31 x2 + k_post), HIP events around each step"},
+            "fill_iters_max": max(iters),
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))   # the box's CPU share for one GPU is 16
+        print(json.dumps(line))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+"""Python host side of the C ABI: mirrors the reference's two entry points.
+
+    img_completion(sparse, extr=False, blur_type="gaussian") -> dense
+        reference: src/DC_lidar_only/img_completion.cpp:17-20
+    interpolate_with_superpixels(labels, sparse, blur_type="gaussian", use_superpixel=1) -> dense
+        reference: src/DC_lidar_camera/img_completion_lc.cpp:34-38
+
+numpy arrays go through the host entry point (dcmt_complete_f32: H2D, kernels, D2H, exact
+hole-closure loop); torch CUDA tensors go through the device entry point on torch's current
+stream (dcmt_complete_f32_dev: asynchronous).  PyTorch is only the owner of device memory
+here.  All arithmetic happens in csrc/ (HIP); there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DcmtError(RuntimeError):
+    def __init__(self, status: int, what: str = ""):
+        super().__init__(f"{what}: {L.strerror(status)} (status {status})")
+        self.status = status
+
+
+def make_params(k0="as_compiled", blur_type: str = "gaussian", stop_after: int = L.STAGE_FINAL,
+                max_fill_iters: int = 64, spec_fill_iters: int = 1, verbose: bool = False,
+                max_depth: float = 100.0, valid_thresh: float = 0.1) -> L.Params:
+    p = L.Params()
+    L.lib().dcmt_default_params(ctypes.byref(p))
+    if isinstance(k0, str):
+        if k0 == "diamond":
+            L.lib().dcmt_k0_diamond(p.k0)
+        elif k0 != "as_compiled":
+            raise ValueError("k0 must be 'as_compiled', 'diamond' or a 5x5 array")
+    else:
+        arr = np.asarray(k0, dtype=np.uint8).reshape(25)
+        for i in range(25):
+            p.k0[i] = int(arr[i])
+    # the reference compares strings: "bilateral" / "gaussian" / anything else = no blur
+    p.blur = {"gaussian": L.BLUR_GAUSSIAN, "bilateral": L.BLUR_BILATERAL}.get(blur_type, L.BLUR_NONE)
+    p.stop_after = int(stop_after)
+    p.max_fill_iters = int(max_fill_iters)
+    p.spec_fill_iters = int(spec_fill_iters)
+    p.verbose = int(bool(verbose))
+    p.max_depth = float(max_depth)
+    p.valid_thresh = float(valid_thresh)
+    return p
+
+
+class Context:
+    """One dcmt_ctx: bound to one GPU, owns the device scratch.  Not thread-safe."""
+
+    def __init__(self, device: int = 0, max_rows: int = 352, max_cols: int = 1216, max_batch: int = 1):
+        self._h = ctypes.c_void_p()
+        self.device, self.max_rows, self.max_cols, self.max_batch = device, max_rows, max_cols, max_batch
+        st = L.lib().dcmt_create(device, max_rows, max_cols, max_batch, ctypes.byref(self._h))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_create")
+
+    def close(self):
+        if self._h:
+            L.lib().dcmt_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- host arrays ------------------------------------------------------------
+    def complete(self, sparse: np.ndarray, params: L.Params | None = None, labels: np.ndarray | None = None,
+                 n_labels: int = 0, use_superpixel: int = 1, allow_not_converged: bool = False) -> np.ndarray:
+        """sparse: f32 [rows][cols] or [batch][rows][cols] (any row stride); returns a new array."""
+        p = params or make_params()
+        src = np.asarray(sparse, dtype=np.float32)
+        single = src.ndim == 2
+        if single:
+            src = src[None]
+        if src.ndim != 3 or src.strides[2] != 4:
+            src = np.ascontiguousarray(src)
+        b, r, c = src.shape
+        dst = np.empty((b, r, c), dtype=np.float32)
+        if labels is None:
+            st = L.lib().dcmt_complete_f32(self._h, src.ctypes.data, src.strides[1], src.strides[0],
+                                           dst.ctypes.data, dst.strides[1], dst.strides[0], r, c, b, ctypes.byref(p))
+        else:
+            lab = np.ascontiguousarray(np.asarray(labels, dtype=np.int32).reshape(b, r, c))
+            st = L.lib().dcmt_complete_labeled_f32(self._h, src.ctypes.data, src.strides[1], src.strides[0],
+                                                   lab.ctypes.data, lab.strides[1], lab.strides[0], int(n_labels),
+                                                   dst.ctypes.data, dst.strides[1], dst.strides[0], r, c, b,
+                                                   ctypes.byref(p), int(use_superpixel))
+        if st != L.OK and not (allow_not_converged and st == L.E_NOT_CONVERGED):
+            raise DcmtError(st, "dcmt_complete_f32")
+        self.last_status = st
+        return dst[0] if single else dst
+
+    # ---- device tensors (torch only as the owner of device memory) ----------------
+    def complete_dev(self, d_src, d_dst=None, params: L.Params | None = None, d_labels=None, n_labels: int = 0,
+                     use_superpixel: int = 1, stream: int | None = None):
+        """d_src/d_dst: contiguous f32 CUDA tensors [batch][rows][cols] (or [rows][cols]) on this
+        context's GPU.  Enqueues on `stream` (a hipStream_t as int; default torch's current stream)
+        and returns immediately."""
+        import torch
+        p = params or make_params()
+        assert d_src.is_cuda and d_src.dtype == torch.float32 and d_src.is_contiguous()
+        if d_dst is None:
+            d_dst = torch.empty_like(d_src)
+        assert d_dst.is_cuda and d_dst.dtype == torch.float32 and d_dst.is_contiguous() and d_dst.shape == d_src.shape
+        shp = d_src.shape if d_src.dim() == 3 else (1,) + tuple(d_src.shape)
+        b, r, c = shp
+        if stream is None:
+            stream = torch.cuda.current_stream(d_src.device).cuda_stream
+        if d_labels is None:
+            st = L.lib().dcmt_complete_f32_dev(self._h, d_src.data_ptr(), d_dst.data_ptr(), r, c, b, ctypes.byref(p),
+                                               ctypes.c_void_p(stream))
+        else:
+            assert d_labels.is_cuda and d_labels.dtype == torch.int32 and d_labels.is_contiguous()
+            st = L.lib().dcmt_complete_labeled_f32_dev(self._h, d_src.data_ptr(), d_labels.data_ptr(), int(n_labels),
+                                                       d_dst.data_ptr(), r, c, b, ctypes.byref(p), int(use_superpixel),
+                                                       ctypes.c_void_p(stream))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_complete_f32_dev")
+        return d_dst
+
+    def last_fill_iters(self, n: int):
+        out = (ctypes.c_int * n)()
+        st = L.lib().dcmt_last_fill_iters(self._h, out, n)
+        if st not in (L.OK, L.E_NOT_CONVERGED):
+            raise DcmtError(st, "dcmt_last_fill_iters")
+        return list(out), st
+
+    def last_holes_after_extend(self, n: int):
+        out = (ctypes.c_int * n)()
+        st = L.lib().dcmt_last_holes_after_extend(self._h, out, n)
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_last_holes_after_extend")
+        return list(out)
+
+
+_default_ctx: dict = {}
+
+
+def _ctx_for(rows: int, cols: int, batch: int, device: int = 0) -> Context:
+    key = device
+    c = _default_ctx.get(key)
+    if c is None or c.max_rows < rows or c.max_cols < cols or c.max_batch < batch:
+        if c is not None:
+            c.close()
+        c = Context(device, max(rows, 352), max(cols, 1216), max(batch, 1))
+        _default_ctx[key] = c
+    return c
+
+
+def img_completion(sparse_r_img: np.ndarray, extr: bool = False, blur_type: str = "gaussian", **kw) -> np.ndarray:
+    """Drop-in for the reference's img_completion (LO/img_completion.cpp:17): returns dense_r_img.
+    `extr` is accepted and ignored, as in the reference (:19, never read)."""
+    a = np.asarray(sparse_r_img, dtype=np.float32)
+    b = 1 if a.ndim == 2 else a.shape[0]
+    return _ctx_for(a.shape[-2], a.shape[-1], b).complete(a, make_params(blur_type=blur_type, **kw))
+
+
+def interpolate_with_superpixels(labels: np.ndarray, n_labels: int, sparse_r_img: np.ndarray,
+                                 blur_type: str = "gaussian", use_superpixel: int = 1, **kw) -> np.ndarray:
+    """Drop-in for LC/img_completion_lc.cpp:34.  `labels` is int32 [rows][cols] (the reference's
+    Slic::clusters is [col][row]: pass clusters.T), n_labels = slic.centers.size().  blur_type is
+    accepted and ignored, as in the reference (:37, :183 always blurs)."""
+    a = np.asarray(sparse_r_img, dtype=np.float32)
+    b = 1 if a.ndim == 2 else a.shape[0]
+    return _ctx_for(a.shape[-2], a.shape[-1], b).complete(a, make_params(blur_type="gaussian", **kw), labels=labels,
+                                                          n_labels=n_labels, use_superpixel=use_superpixel)

@@ -1,0 +1,377 @@
+// dcmt.hip -- implementation of the C ABI in include/dcmt.h on gfx950 (MI355X).
+//
+// Host side of the hot path: context (device scratch owned per GPU), launch sequencing of
+// the kernels in dcmt_kernels_v1.h / dcmt_kernels_fused.h, and the host<->device copies of
+// the cv::Mat entry point.  No PyTorch, no OpenCV, no CPU fallback: if there is no gfx950
+// device every entry point fails with DCMT_E_NO_DEVICE / DCMT_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "dcmt.h"
+#include "dcmt_kernels_v1.h"
+
+using namespace dcmt;
+
+struct dcmt_ctx {
+    int device = 0;
+    int max_rows = 0, max_cols = 0, max_batch = 0;
+    size_t frame_elems = 0;           // max_rows * max_cols
+    // device scratch
+    float* x5 = nullptr;              // [max_batch][rows][cols] : cascade after the small fill
+    float* pp[2] = {nullptr, nullptr};// ping-pong of the large-fill applications
+    int* colstat = nullptr;           // [max_batch][2][cols]
+    int* counters = nullptr;          // [max_batch][kCntStride]
+    // host-entry staging (allocated on first use)
+    float* d_in = nullptr;
+    float* d_out = nullptr;
+    int32_t* d_lab = nullptr;
+    int* h_counters = nullptr;        // pinned
+    hipStream_t own_stream = nullptr;
+    // state of the last call
+    hipStream_t last_stream = nullptr;
+    int last_batch = 0;
+    int last_apps_launched = 0;       // loop applications (app >= 1) enqueued
+    int last_has_loop = 0;            // the call went at least through H8
+    int last_hip_error = 0;
+};
+
+namespace {
+
+constexpr int TH = 32, TW = 64;
+
+#define DCMT_HIP(ctx, call)                                        \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) {                                    \
+            if (ctx) (ctx)->last_hip_error = (int)e_;              \
+            return e_ == hipErrorOutOfMemory ? DCMT_E_NOMEM : DCMT_E_HIP; \
+        }                                                          \
+    } while (0)
+
+uint32_t k0_bits(const uint8_t k0[25])
+{
+    uint32_t b = 0;
+    for (int i = 0; i < 25; ++i) if (k0[i]) b |= 1u << i;
+    return b;
+}
+
+int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, int cols, int batch, const dcmt_params* p)
+{
+    if (!ctx || !a || !b || !p) return DCMT_E_INVALID;
+    if (rows < 1 || cols < 1 || batch < 1) return DCMT_E_INVALID;
+    if (batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
+    if (p->blur == DCMT_BLUR_BILATERAL) return DCMT_E_UNSUPPORTED;
+    if (p->blur != DCMT_BLUR_NONE && p->blur != DCMT_BLUR_GAUSSIAN) return DCMT_E_INVALID;
+    if (p->max_fill_iters < 1 || p->max_fill_iters > kMaxIters) return DCMT_E_INVALID;
+    if (p->spec_fill_iters < 0 || p->spec_fill_iters > kMaxIters) return DCMT_E_INVALID;
+    if (p->stop_after < DCMT_STAGE_INVERT || p->stop_after > DCMT_STAGE_FINAL) return DCMT_E_INVALID;
+    if (k0_bits(p->k0) == 0) return DCMT_E_INVALID;
+    return DCMT_OK;
+}
+
+dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
+
+// Enqueues the cascade on `st`.  sync_loop: run the hole-closure loop exactly as the
+// reference would, reading the hole counters back between applications (host entry
+// points); otherwise enqueue p->spec_fill_iters applications speculatively.
+int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_labels, int use_superpixel,
+              float* d_dst, int rows, int cols, int batch, const dcmt_params* p, bool force_gaussian,
+              hipStream_t st, bool sync_loop)
+{
+    const dim3 grid = tile_grid(rows, cols, batch), block(kThreads);
+    const uint32_t kb = k0_bits(p->k0);
+    const int stop = p->stop_after;
+    const int blur = force_gaussian ? (int)DCMT_BLUR_GAUSSIAN : p->blur;
+    ctx->last_stream = st;
+    ctx->last_batch = batch;
+    ctx->last_apps_launched = 0;
+    ctx->last_has_loop = 0;
+
+    {
+        const long n = (long)batch * (2L * cols + kCntStride);
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, st, ctx->colstat, ctx->counters, cols, batch);
+    }
+    const int dump = stop <= DCMT_STAGE_CLOSE5 ? stop : 0;
+    if (d_labels && use_superpixel) {
+        hipLaunchKernelGGL((k_pre_labeled_v1<TH, TW>), grid, block, 0, st, d_src, d_labels, n_labels,
+                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, d_dst, rows, cols,
+                           p->max_depth, p->valid_thresh, kb, dump);
+    } else {
+        hipLaunchKernelGGL((k_pre_v1<TH, TW>), grid, block, 0, st, d_src,
+                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, d_dst, rows, cols,
+                           p->max_depth, p->valid_thresh, kb, dump);
+    }
+    DCMT_HIP(ctx, hipGetLastError());
+    if (stop <= DCMT_STAGE_FILL7) return DCMT_OK;
+
+    // H6 + H7
+    if (stop == DCMT_STAGE_EXTEND) {
+        hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->x5, d_dst, ctx->colstat, ctx->counters,
+                           rows, cols, p->valid_thresh, 0, 1);
+        DCMT_HIP(ctx, hipGetLastError());
+        return DCMT_OK;
+    }
+    hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->x5,
+                       stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0], ctx->colstat, ctx->counters,
+                       rows, cols, p->valid_thresh, 0, 0);
+    DCMT_HIP(ctx, hipGetLastError());
+    if (stop == DCMT_STAGE_FILL31) return DCMT_OK;
+
+    // H8
+    ctx->last_has_loop = 1;
+    int rc = DCMT_OK;
+    int apps = 0;
+    if (sync_loop) {
+        // Iteration i of the reference's loop (LO :146-166) counts the holes left by application
+        // i-1, fills them (application i: a no-op when there are none) and stops when it saw
+        // none; the cap bounds i.  Frames without holes skip an application on the device.
+        for (int i = 1;; ++i) {
+            DCMT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(int) * (size_t)batch * kCntStride,
+                                         hipMemcpyDeviceToHost, st));
+            DCMT_HIP(ctx, hipStreamSynchronize(st));
+            bool any = false;
+            for (int f = 0; f < batch; ++f) {
+                const int n_i = ctx->h_counters[(size_t)f * kCntStride + i];   // [1 + (i-1)]
+                any |= n_i > 0;
+                if (p->verbose) std::printf("%d\n", n_i);                       // LO :161
+            }
+            if (!any) break;
+            hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->pp[(i - 1) & 1], ctx->pp[i & 1],
+                               ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, i, 0);
+            DCMT_HIP(ctx, hipGetLastError());
+            apps = i;
+            if (i >= p->max_fill_iters) { rc = DCMT_E_NOT_CONVERGED; break; }
+        }
+    } else {
+        int n = p->spec_fill_iters;
+        if (n > p->max_fill_iters) n = p->max_fill_iters;
+        for (apps = 1; apps <= n; ++apps) {
+            hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->pp[(apps - 1) & 1], ctx->pp[apps & 1],
+                               ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, apps, 0);
+        }
+        apps = n;
+        DCMT_HIP(ctx, hipGetLastError());
+    }
+    ctx->last_apps_launched = apps;
+
+    const int mode = stop <= DCMT_STAGE_FILLLOOP ? 8 : stop;
+    hipLaunchKernelGGL((k_post_v1<TH, TW>), grid, block, 0, st, ctx->pp[0], ctx->pp[1], d_dst, ctx->counters, apps,
+                       rows, cols, p->max_depth, p->valid_thresh, blur, mode);
+    DCMT_HIP(ctx, hipGetLastError());
+    return rc;
+}
+
+int ensure_host_staging(dcmt_ctx* ctx, bool labels)
+{
+    const size_t bytes = sizeof(float) * ctx->frame_elems * (size_t)ctx->max_batch;
+    if (!ctx->d_in) DCMT_HIP(ctx, hipMalloc((void**)&ctx->d_in, bytes));
+    if (!ctx->d_out) DCMT_HIP(ctx, hipMalloc((void**)&ctx->d_out, bytes));
+    if (labels && !ctx->d_lab) DCMT_HIP(ctx, hipMalloc((void**)&ctx->d_lab, bytes));
+    if (!ctx->own_stream) DCMT_HIP(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    return DCMT_OK;
+}
+
+int host_call(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int32_t* labels, size_t lrs, size_t lfs,
+              int n_labels, int use_superpixel, float* dst, size_t drs, size_t dfs, int rows, int cols, int batch,
+              const dcmt_params* p, bool force_gaussian)
+{
+    int rc = check_params(ctx, src, dst, rows, cols, batch, p);
+    if (rc != DCMT_OK) return rc;
+    if (srs < sizeof(float) * (size_t)cols || drs < sizeof(float) * (size_t)cols) return DCMT_E_INVALID;
+    if (labels && lrs < sizeof(int32_t) * (size_t)cols) return DCMT_E_INVALID;
+    DCMT_HIP(ctx, hipSetDevice(ctx->device));
+    rc = ensure_host_staging(ctx, labels != nullptr);
+    if (rc != DCMT_OK) return rc;
+    hipStream_t st = ctx->own_stream;
+    const size_t row_b = sizeof(float) * (size_t)cols, frame_b = row_b * rows;
+    if (p->verbose) std::printf("NUMERO ROWS, COLS: %d %d\n", rows, cols);   // LO :29
+    for (int f = 0; f < batch; ++f) {
+        DCMT_HIP(ctx, hipMemcpy2DAsync((char*)ctx->d_in + f * frame_b, row_b, (const char*)src + f * sfs, srs, row_b, rows,
+                                       hipMemcpyHostToDevice, st));
+        if (labels)
+            DCMT_HIP(ctx, hipMemcpy2DAsync((char*)ctx->d_lab + f * frame_b, row_b, (const char*)labels + f * lfs, lrs, row_b,
+                                           rows, hipMemcpyHostToDevice, st));
+    }
+    const int chain_rc = run_chain(ctx, ctx->d_in, labels ? ctx->d_lab : nullptr, n_labels, use_superpixel, ctx->d_out,
+                                   rows, cols, batch, p, force_gaussian, st, true);
+    if (chain_rc != DCMT_OK && chain_rc != DCMT_E_NOT_CONVERGED) return chain_rc;
+    for (int f = 0; f < batch; ++f)
+        DCMT_HIP(ctx, hipMemcpy2DAsync((char*)dst + f * dfs, drs, (const char*)ctx->d_out + f * frame_b, row_b, row_b, rows,
+                                       hipMemcpyDeviceToHost, st));
+    DCMT_HIP(ctx, hipStreamSynchronize(st));
+    return chain_rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcmt_version(void) { return DCMT_VERSION; }
+
+int dcmt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* dcmt_strerror(int s)
+{
+    switch (s) {
+        case DCMT_OK: return "ok";
+        case DCMT_E_INVALID: return "invalid argument";
+        case DCMT_E_UNSUPPORTED: return "unsupported (bilateral blur: the reference's in-place cv::bilateralFilter call throws)";
+        case DCMT_E_NOMEM: return "out of memory";
+        case DCMT_E_HIP: return "HIP runtime error";
+        case DCMT_E_NOT_CONVERGED: return "hole-closure loop hit max_fill_iters with holes left";
+        case DCMT_E_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+void dcmt_k0_as_compiled(uint8_t k0[25])
+{
+    // reference img_completion.cpp:71-77: the first 25 bytes of `int d[5][5]` = {0,0,1,0,0, 0,1,...}
+    // on a little-endian host: only byte 8 (row 1, col 3) and byte 24 (row 4, col 4) are non-zero
+    std::memset(k0, 0, 25);
+    k0[1 * 5 + 3] = 1;
+    k0[4 * 5 + 4] = 1;
+}
+
+void dcmt_k0_diamond(uint8_t k0[25])
+{
+    static const uint8_t d[25] = {0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 0, 0, 0, 1, 0, 0};
+    std::memcpy(k0, d, 25);
+}
+
+void dcmt_default_params(dcmt_params* p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->max_depth = 100.0f;
+    p->valid_thresh = 0.1f;
+    dcmt_k0_as_compiled(p->k0);
+    p->blur = DCMT_BLUR_GAUSSIAN;
+    p->max_fill_iters = kMaxIters;
+    p->spec_fill_iters = 1;
+    p->stop_after = DCMT_STAGE_FINAL;
+    p->verbose = 0;
+}
+
+int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx** out)
+{
+    if (!out || max_rows < 1 || max_cols < 1 || max_batch < 1 || max_batch > 65535) return DCMT_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return DCMT_E_NO_DEVICE;
+    if (device < 0 || device >= n) return DCMT_E_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DCMT_E_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DCMT_E_NO_DEVICE;   // kernels are built for gfx950 only
+    dcmt_ctx* ctx = new (std::nothrow) dcmt_ctx();
+    if (!ctx) return DCMT_E_NOMEM;
+    ctx->device = device;
+    ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
+    ctx->frame_elems = (size_t)max_rows * max_cols;
+    auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
+    if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
+    const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;
+    if (hipMalloc((void**)&ctx->x5, plane) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->pp[0], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipHostMalloc((void**)&ctx->h_counters, sizeof(int) * (size_t)kCntStride * max_batch, hipHostMallocDefault) != hipSuccess)
+        return fail(DCMT_E_NOMEM);
+    *out = ctx;
+    return DCMT_OK;
+}
+
+void dcmt_destroy(dcmt_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
+    (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
+    (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters);
+    (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    delete ctx;
+}
+
+int dcmt_complete_f32(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, float* dst, size_t drs, size_t dfs,
+                      int rows, int cols, int batch, const dcmt_params* params)
+{
+    return host_call(ctx, src, srs, sfs, nullptr, 0, 0, 0, 0, dst, drs, dfs, rows, cols, batch, params, false);
+}
+
+int dcmt_complete_labeled_f32(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int32_t* labels, size_t lrs,
+                              size_t lfs, int n_labels, float* dst, size_t drs, size_t dfs, int rows, int cols, int batch,
+                              const dcmt_params* params, int use_superpixel)
+{
+    if (!labels) return DCMT_E_INVALID;
+    return host_call(ctx, src, srs, sfs, labels, lrs, lfs, n_labels, use_superpixel, dst, drs, dfs, rows, cols, batch,
+                     params, true);
+}
+
+int dcmt_complete_f32_dev(dcmt_ctx* ctx, const float* d_src, float* d_dst, int rows, int cols, int batch,
+                          const dcmt_params* params, void* stream)
+{
+    int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
+    if (rc != DCMT_OK) return rc;
+    return run_chain(ctx, d_src, nullptr, 0, 0, d_dst, rows, cols, batch, params, false, (hipStream_t)stream, false);
+}
+
+int dcmt_complete_labeled_f32_dev(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_labels, float* d_dst,
+                                  int rows, int cols, int batch, const dcmt_params* params, int use_superpixel, void* stream)
+{
+    int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
+    if (rc != DCMT_OK) return rc;
+    if (!d_labels) return DCMT_E_INVALID;
+    return run_chain(ctx, d_src, d_labels, n_labels, use_superpixel, d_dst, rows, cols, batch, params, true,
+                     (hipStream_t)stream, false);
+}
+
+static int read_counters(dcmt_ctx* ctx)
+{
+    DCMT_HIP(ctx, hipSetDevice(ctx->device));
+    DCMT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(int) * (size_t)ctx->last_batch * kCntStride,
+                                 hipMemcpyDeviceToHost, ctx->last_stream));
+    DCMT_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    return DCMT_OK;
+}
+
+int dcmt_last_fill_iters(dcmt_ctx* ctx, int* out, int n)
+{
+    if (!ctx || !out || n < 0 || n > ctx->last_batch) return DCMT_E_INVALID;
+    if (!ctx->last_has_loop) return DCMT_E_INVALID;
+    int rc = read_counters(ctx);
+    if (rc != DCMT_OK) return rc;
+    for (int f = 0; f < n; ++f) {
+        const int* c = ctx->h_counters + (size_t)f * kCntStride;
+        int a = 0;
+        while (a < ctx->last_apps_launched && c[1 + a] > 0) ++a;
+        if (c[1 + a] > 0) { out[f] = -1; rc = DCMT_E_NOT_CONVERGED; }
+        else out[f] = a + 1;
+    }
+    return rc;
+}
+
+int dcmt_last_holes_after_extend(dcmt_ctx* ctx, int* out, int n)
+{
+    if (!ctx || !out || n < 0 || n > ctx->last_batch) return DCMT_E_INVALID;
+    int rc = read_counters(ctx);
+    if (rc != DCMT_OK) return rc;
+    for (int f = 0; f < n; ++f) out[f] = ctx->h_counters[(size_t)f * kCntStride];
+    return DCMT_OK;
+}
+
+int dcmt_last_hip_error(const dcmt_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+}  // extern "C"

@@ -1,0 +1,552 @@
+// dcmt_kernels_v1.h -- "staged" gfx950 kernels: one launch per stage group, every stage
+// staging its tile + halo in LDS.  These are the GENERAL path: any image size, any 5x5
+// first element, the label-masked variant, per-stage dumps for parity probes and the
+// hole-closure loop.  The fused fast path for the default configuration lives in
+// dcmt_kernels_fused.h and falls back to these kernels frame by frame.
+//
+// Stage names H2..H11 follow SURVEY.md section 8a; LO = reference
+// src/DC_lidar_only/img_completion.cpp, LC = src/DC_lidar_camera/img_completion_lc.cpp.
+//
+// Conventions shared by all kernels here:
+//  * grid = (tiles_x, tiles_y, batch); 256 threads (4 wave64) per workgroup;
+//  * an LDS "region" is the output tile grown by the stage group's total radius; region
+//    coordinates (y,x) map to image coordinates (ty0+y, tx0+x);
+//  * positions of a region that fall outside the image hold the border value of the
+//    stage that will read them next (-FLT_MAX before a dilate, +FLT_MAX before an erode:
+//    cv::dilate / cv::erode with BORDER_CONSTANT and the default border value), so the
+//    window loops need no bounds tests;
+//  * LDS pitches are odd so that row-wise and column-wise walks are both conflict-free
+//    for ds_read_b32 (bank = dword address mod 32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "median_net25.h"
+
+namespace dcmt {
+
+constexpr int kThreads = 256;
+constexpr int kMaxIters = 64;          // hard cap of dcmt_params.max_fill_iters
+constexpr int kCntStride = kMaxIters + 4;  // ints per frame in the counter block
+
+// counter block layout per frame (ints):
+//  [0]            holes seen by H7 (= holes after the column extension)
+//  [1 + k]        holes left after fill application k (k = 0 is H7 itself, k >= 1 the loop)
+__device__ __forceinline__ int* frame_counters(int* counters, int f) { return counters + (size_t)f * kCntStride; }
+
+__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_fminf(a, b); }
+
+// for every (y,x) in [y0,y1) x [x0,x1), consecutive threads on consecutive x
+template <typename F>
+__device__ __forceinline__ void for_rect(int y0, int y1, int x0, int x1, F f)
+{
+    const int w = x1 - x0, n = (y1 - y0) * w;
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const int y = i / w, x = i - y * w;
+        f(y0 + y, x0 + x);
+    }
+}
+
+__device__ __forceinline__ float invert_valid(float v, float max_depth, float thr)
+{
+    return v >= thr ? max_depth - v : v;     // LO :59-63 / :194-198
+}
+
+// ---------------------------------------------------------------------------------
+// init: column statistics and counters for one call
+// ---------------------------------------------------------------------------------
+__global__ void k_init(int* __restrict__ colstat, int* __restrict__ counters, int cols, int batch)
+{
+    const long n_cs = (long)batch * 2 * cols;
+    const long n_ct = (long)batch * kCntStride;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_cs + n_ct; i += (long)gridDim.x * blockDim.x) {
+        if (i < n_cs) {
+            const long f2 = i / cols;                 // frame*2 + which
+            colstat[i] = (f2 & 1) ? -1 : 0x7fffffff;  // [f][0][c] = first valid row (min), [f][1][c] = last (max)
+        } else {
+            counters[i - n_cs] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_pre_v1: H2 invert, H3 dilate(k0), H4 close 5x5, H5 7x7 small fill  ->  X5,
+//           plus per-column first/last valid row of X5 (input of H6).
+// Total radius 2 + 2 + 2 + 3 = 9.
+// ---------------------------------------------------------------------------------
+template <int TH, int TW>
+struct PreGeom {
+    static constexpr int R = 9, RH = TH + 2 * R, RW = TW + 2 * R, P = RW | 1;
+};
+
+// Shared tail of k_pre_v1 / k_pre_labeled_v1: B holds X4 on [6,RH-6)x[6,RW-6) with
+// -FLT_MAX outside the image; A is scratch.  Computes X5 on the tile and the column stats.
+template <int TH, int TW>
+__device__ __forceinline__ void small_fill_and_stats(float* A, float* B, int* smin, int* smax,
+                                                     float* __restrict__ x5f, int* __restrict__ colstat_f,
+                                                     int rows, int cols, int ty0, int tx0, float thr)
+{
+    using G = PreGeom<TH, TW>;
+    constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
+    // H5 (LO :88-100): s = dilate7(x); x = x < 0.1 ? s : x
+    for_rect(6, RH - 6, R, RW - R, [&](int y, int x) {
+        const float* b = B + y * P + x;
+        float m = fmax2(fmax2(b[-3], b[-2]), fmax2(b[-1], b[0]));
+        m = fmax2(m, fmax2(fmax2(b[1], b[2]), b[3]));
+        A[y * P + x] = m;
+    });
+    for (int i = threadIdx.x; i < TW; i += kThreads) { smin[i] = 0x7fffffff; smax[i] = -1; }
+    __syncthreads();
+    for_rect(R, RH - R, R, RW - R, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy >= rows || gx >= cols) return;     // tile origin is inside the image: gy,gx >= 0 here
+        const float* a = A + y * P + x;
+        float s = fmax2(fmax2(a[-3 * P], a[-2 * P]), fmax2(a[-P], a[0]));
+        s = fmax2(s, fmax2(fmax2(a[P], a[2 * P]), a[3 * P]));
+        const float x4 = B[y * P + x];
+        const float v = x4 < thr ? s : x4;
+        x5f[(size_t)gy * cols + gx] = v;
+        if (v >= thr) {                           // LO :113,:117 `> 0.1`
+            atomicMin(&smin[x - R], gy);
+            atomicMax(&smax[x - R], gy);
+        }
+    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < TW; i += kThreads) {
+        const int gx = tx0 + R + i;
+        if (gx < cols && smax[i] >= 0) {
+            atomicMin(&colstat_f[gx], smin[i]);
+            atomicMax(&colstat_f[cols + gx], smax[i]);
+        }
+    }
+}
+
+template <int TH, int TW>
+__device__ __forceinline__ void dump_plane(const float* plane, float* __restrict__ dstf,
+                                           int rows, int cols, int ty0, int tx0)
+{
+    using G = PreGeom<TH, TW>;
+    for_rect(G::R, G::RH - G::R, G::R, G::RW - G::R, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy < rows && gx < cols) dstf[(size_t)gy * cols + gx] = plane[y * G::P + x];
+    });
+}
+
+template <int TH, int TW>
+__global__ __launch_bounds__(kThreads)
+void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __restrict__ colstat,
+              float* __restrict__ dump, int rows, int cols, float max_depth, float thr,
+              uint32_t k0bits, int dump_stage)
+{
+    using G = PreGeom<TH, TW>;
+    constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
+    __shared__ float A[RH * P];
+    __shared__ float B[RH * P];
+    __shared__ int smin[TW], smax[TW];
+
+    const int f = blockIdx.z;
+    const int ty0 = blockIdx.y * TH - R, tx0 = blockIdx.x * TW - R;
+    const size_t fo = (size_t)f * rows * cols;
+    const float* s = src + fo;
+
+    // H2 (LO :55-67) on load; outside the image: border value of the dilate that follows
+    for_rect(0, RH, 0, RW, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        float v = -FLT_MAX;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = invert_valid(s[(size_t)gy * cols + gx], max_depth, thr);
+        A[y * P + x] = v;
+    });
+    __syncthreads();
+    if (dump_stage == 2) { dump_plane<TH, TW>(A, dump + fo, rows, cols, ty0, tx0); return; }
+
+    // H3 (LO :71-80): dst(p) = max over non-zero taps k of src(p + k - anchor)
+    for_rect(2, RH - 2, 2, RW - 2, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        float m = -FLT_MAX;
+#pragma unroll
+        for (int t = 0; t < 25; ++t)
+            if ((k0bits >> t) & 1u) m = fmax2(m, A[(y + t / 5 - 2) * P + x + t % 5 - 2]);
+        const bool in = gy >= 0 && gy < rows && gx >= 0 && gx < cols;
+        B[y * P + x] = in ? m : -FLT_MAX;
+    });
+    __syncthreads();
+    if (dump_stage == 3) { dump_plane<TH, TW>(B, dump + fo, rows, cols, ty0, tx0); return; }
+
+    // H4 (LO :84-85) MORPH_CLOSE = dilate 5x5 then erode 5x5, each as row pass + column pass
+    for_rect(2, RH - 2, 4, RW - 4, [&](int y, int x) {
+        const float* b = B + y * P + x;
+        A[y * P + x] = fmax2(fmax2(fmax2(b[-2], b[-1]), fmax2(b[0], b[1])), b[2]);
+    });
+    __syncthreads();
+    for_rect(4, RH - 4, 4, RW - 4, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        const float* a = A + y * P + x;
+        const float m = fmax2(fmax2(fmax2(a[-2 * P], a[-P]), fmax2(a[0], a[P])), a[2 * P]);
+        const bool in = gy >= 0 && gy < rows && gx >= 0 && gx < cols;
+        B[y * P + x] = in ? m : FLT_MAX;          // border value of the erode
+    });
+    __syncthreads();
+    for_rect(4, RH - 4, 6, RW - 6, [&](int y, int x) {
+        const float* b = B + y * P + x;
+        A[y * P + x] = fmin2(fmin2(fmin2(b[-2], b[-1]), fmin2(b[0], b[1])), b[2]);
+    });
+    __syncthreads();
+    for_rect(6, RH - 6, 6, RW - 6, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        const float* a = A + y * P + x;
+        const float m = fmin2(fmin2(fmin2(a[-2 * P], a[-P]), fmin2(a[0], a[P])), a[2 * P]);
+        const bool in = gy >= 0 && gy < rows && gx >= 0 && gx < cols;
+        B[y * P + x] = in ? m : -FLT_MAX;         // border value of the 7x7 dilate
+    });
+    __syncthreads();
+    if (dump_stage == 4) { dump_plane<TH, TW>(B, dump + fo, rows, cols, ty0, tx0); return; }
+
+    small_fill_and_stats<TH, TW>(A, B, smin, smax, x5 + fo, colstat + (size_t)f * 2 * cols, rows, cols, ty0, tx0, thr);
+}
+
+// ---------------------------------------------------------------------------------
+// k_pre_labeled_v1: LC variant.  H2, then for every label c present near the tile
+//   region = x * [label == c]  (other in-image pixels 0, LC :94-95)
+//   region = erode5(dilate5(dilate_k0(region)))   (LC :97-100)
+//   x[label == c] = region[label == c]            (LC :101)
+// then H5 and the column statistics exactly as k_pre_v1.  Labels are disjoint and each
+// write-back only depends on the pre-loop values of its own label, so the label order is
+// irrelevant and every tile can process just the labels it contains.
+// ---------------------------------------------------------------------------------
+template <int TH, int TW>
+__global__ __launch_bounds__(kThreads)
+void k_pre_labeled_v1(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
+                      float* __restrict__ x5, int* __restrict__ colstat, float* __restrict__ dump,
+                      int rows, int cols, float max_depth, float thr, uint32_t k0bits, int dump_stage)
+{
+    using G = PreGeom<TH, TW>;
+    constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
+    __shared__ float X0[RH * P];     // H2 output (never modified)
+    __shared__ int   L[RH * P];      // labels; -2 outside the image
+    __shared__ float A[RH * P];
+    __shared__ float B[RH * P];
+    __shared__ float X4[RH * P];     // result of the masked stage, needed on [6,RH-6)x[6,RW-6)
+    __shared__ int smin[TW], smax[TW];
+    __shared__ int s_next;
+
+    const int f = blockIdx.z;
+    const int ty0 = blockIdx.y * TH - R, tx0 = blockIdx.x * TW - R;
+    const size_t fo = (size_t)f * rows * cols;
+    const float* s = src + fo;
+    const int32_t* lab = labels + fo;
+
+    for_rect(0, RH, 0, RW, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        float v = -FLT_MAX;
+        int l = -2;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) {
+            v = invert_valid(s[(size_t)gy * cols + gx], max_depth, thr);
+            l = lab[(size_t)gy * cols + gx];
+            if (l < 0 || l >= n_labels) l = -1;     // never matched by the loop `c in [0,n)` (LC :78)
+        }
+        X0[y * P + x] = v;
+        L[y * P + x] = l;
+        X4[y * P + x] = v;                          // unlabeled pixels keep the H2 value
+    });
+    __syncthreads();
+    if (dump_stage == 2) { dump_plane<TH, TW>(X0, dump + fo, rows, cols, ty0, tx0); return; }
+
+    int cur = -1;
+    for (;;) {
+        // next label > cur present on [6,RH-6)x[6,RW-6)
+        if (threadIdx.x == 0) s_next = 0x7fffffff;
+        __syncthreads();
+        int mine = 0x7fffffff;
+        for_rect(6, RH - 6, 6, RW - 6, [&](int y, int x) {
+            const int l = L[y * P + x];
+            if (l > cur && l < mine) mine = l;
+        });
+        if (mine != 0x7fffffff) atomicMin(&s_next, mine);
+        __syncthreads();
+        cur = s_next;
+        if (cur == 0x7fffffff) break;
+
+        // masked copy: label pixels keep their value, other in-image pixels are 0,
+        // outside the image the dilate border value
+        for_rect(0, RH, 0, RW, [&](int y, int x) {
+            const int l = L[y * P + x];
+            A[y * P + x] = l == -2 ? -FLT_MAX : (l == cur ? X0[y * P + x] : 0.0f);
+        });
+        __syncthreads();
+        for_rect(2, RH - 2, 2, RW - 2, [&](int y, int x) {
+            float m = -FLT_MAX;
+#pragma unroll
+            for (int t = 0; t < 25; ++t)
+                if ((k0bits >> t) & 1u) m = fmax2(m, A[(y + t / 5 - 2) * P + x + t % 5 - 2]);
+            B[y * P + x] = L[y * P + x] == -2 ? -FLT_MAX : m;
+        });
+        __syncthreads();
+        for_rect(2, RH - 2, 4, RW - 4, [&](int y, int x) {
+            const float* b = B + y * P + x;
+            A[y * P + x] = fmax2(fmax2(fmax2(b[-2], b[-1]), fmax2(b[0], b[1])), b[2]);
+        });
+        __syncthreads();
+        for_rect(4, RH - 4, 4, RW - 4, [&](int y, int x) {
+            const float* a = A + y * P + x;
+            const float m = fmax2(fmax2(fmax2(a[-2 * P], a[-P]), fmax2(a[0], a[P])), a[2 * P]);
+            B[y * P + x] = L[y * P + x] == -2 ? FLT_MAX : m;
+        });
+        __syncthreads();
+        for_rect(4, RH - 4, 6, RW - 6, [&](int y, int x) {
+            const float* b = B + y * P + x;
+            A[y * P + x] = fmin2(fmin2(fmin2(b[-2], b[-1]), fmin2(b[0], b[1])), b[2]);
+        });
+        __syncthreads();
+        for_rect(6, RH - 6, 6, RW - 6, [&](int y, int x) {
+            if (L[y * P + x] != cur) return;
+            const float* a = A + y * P + x;
+            X4[y * P + x] = fmin2(fmin2(fmin2(a[-2 * P], a[-P]), fmin2(a[0], a[P])), a[2 * P]);
+        });
+        __syncthreads();
+    }
+    // X4 outside the image must be the border value of the 7x7 dilate; it is (-FLT_MAX from the load)
+    if (dump_stage == 3 || dump_stage == 4) { dump_plane<TH, TW>(X4, dump + fo, rows, cols, ty0, tx0); return; }
+
+    small_fill_and_stats<TH, TW>(A, X4, smin, smax, x5 + fo, colstat + (size_t)f * 2 * cols, rows, cols, ty0, tx0, thr);
+}
+
+// ---------------------------------------------------------------------------------
+// k_fill31_v1: one application of "s = dilate31(x); x = x < 0.1 ? s : x".
+//   app == 0 : H6 + H7  -- the input is X5 with the column extension (LO :103-129) applied
+//              on load from the per-column first/last valid rows; counts the holes it sees.
+//   app >= 1 : one iteration of the H8 loop (LO :146-166); skipped for frames whose
+//              previous application left no holes (an application without holes changes
+//              nothing, so skipping it is exact).
+// The 31-wide max is built by doubling: windows of 2, 4, 8, 16, then 16 + 16 overlapping.
+// ---------------------------------------------------------------------------------
+template <int TH, int TW>
+struct FillGeom {
+    static constexpr int R = 15, RH = TH + 2 * R, RW = TW + 2 * R, P = RW | 1;
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(kThreads)
+void k_fill31_v1(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ colstat,
+                 int* __restrict__ counters, int rows, int cols, float thr, int app, int dump_extend)
+{
+    using G = FillGeom<TH, TW>;
+    constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
+    __shared__ float A[RH * P];
+    __shared__ float B[RH * P];
+    __shared__ float C[TH * TW];                 // the tile's own input values
+    __shared__ int   cti[RW], cbi[RW];
+    __shared__ float ctv[RW], cbv[RW];
+    __shared__ int   s_before, s_after;
+
+    const int f = blockIdx.z;
+    int* cnt = frame_counters(counters, f);
+    if (app >= 1 && cnt[1 + app - 1] == 0) return;      // uniform per workgroup
+
+    const int ty0 = blockIdx.y * TH - R, tx0 = blockIdx.x * TW - R;
+    const size_t fo = (size_t)f * rows * cols;
+    const float* xin = in + fo;
+
+    if (threadIdx.x == 0) { s_before = 0; s_after = 0; }
+    if (app == 0) {
+        const int* cs = colstat + (size_t)f * 2 * cols;
+        for (int x = threadIdx.x; x < RW; x += kThreads) {
+            const int gx = tx0 + x;
+            int ti = 0, bi = -1; float tv = 0.f, bv = 0.f;
+            if (gx >= 0 && gx < cols) {
+                ti = cs[gx]; bi = cs[cols + gx];
+                if (bi >= 0) { tv = xin[(size_t)ti * cols + gx]; bv = xin[(size_t)bi * cols + gx]; }
+            }
+            cti[x] = ti; cbi[x] = bi; ctv[x] = tv; cbv[x] = bv;
+        }
+    }
+    __syncthreads();
+    for_rect(0, RH, 0, RW, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        float v = -FLT_MAX;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) {
+            v = xin[(size_t)gy * cols + gx];
+            if (app == 0) {
+                // LO :122-127: rows >= last valid take its value, then rows <= first valid take
+                // its value; a column without valid pixels ends as 100 everywhere (:110,:125-127)
+                const int bi = cbi[x];
+                if (bi < 0) v = 100.0f;
+                else if (gy <= cti[x]) v = ctv[x];
+                else if (gy >= bi) v = cbv[x];
+            }
+        }
+        A[y * P + x] = v;
+        if (y >= R && y < RH - R && x >= R && x < RW - R) C[(y - R) * TW + (x - R)] = v;
+    });
+    __syncthreads();
+    if (dump_extend) {
+        for_rect(0, TH, 0, TW, [&](int y, int x) {
+            const int gy = ty0 + R + y, gx = tx0 + R + x;
+            if (gy < rows && gx < cols) out[fo + (size_t)gy * cols + gx] = C[y * TW + x];
+        });
+        return;
+    }
+
+    // row phase: A -> B -> A -> B -> A -> B ; B[y][x] = max A0[y][x .. x+30]
+    float* s0 = A; float* s1 = B;
+    {
+        const int steps[5] = {1, 2, 4, 8, 15};
+        int win = 1;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int st = steps[k];
+            win += st;                            // 2,4,8,16,31
+            for_rect(0, RH, 0, RW - win + 1, [&](int y, int x) {
+                s1[y * P + x] = fmax2(s0[y * P + x], s0[y * P + x + st]);
+            });
+            __syncthreads();
+            float* t = s0; s0 = s1; s1 = t;
+        }
+        // column phase on the TW tile columns (x in [0,TW) after the row phase)
+        win = 1;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int st = steps[k];
+            win += st;
+            for_rect(0, RH - win + 1, 0, TW, [&](int y, int x) {
+                s1[y * P + x] = fmax2(s0[y * P + x], s0[(y + st) * P + x]);
+            });
+            __syncthreads();
+            float* t = s0; s0 = s1; s1 = t;
+        }
+    }
+    // s0[y][x], y < TH, x < TW = dilate31 at tile pixel (y,x)
+    int before = 0, after = 0;
+    for_rect(0, TH, 0, TW, [&](int y, int x) {
+        const int gy = ty0 + R + y, gx = tx0 + R + x;
+        if (gy >= rows || gx >= cols) return;
+        const float v = C[y * TW + x];
+        const bool hole = v < thr;                // LO :140 / :154
+        const float o = hole ? s0[y * P + x] : v;
+        out[fo + (size_t)gy * cols + gx] = o;
+        before += hole;
+        after += o < thr;
+    });
+    if (before) atomicAdd(&s_before, before);
+    if (after) atomicAdd(&s_after, after);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (app == 0 && s_before) atomicAdd(&cnt[0], s_before);
+        if (s_after) atomicAdd(&cnt[1 + app], s_after);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_post_v1: H9 median 5x5 (BORDER_REPLICATE), H10 Gaussian [1 4 6 4 1]/16 separable
+//            (BORDER_REFLECT_101) + masked select, H11 invert.  Reads the buffer that holds
+//            the frame after its last fill application.
+// mode: 8 = copy only (probe of H8), 9 = stop after the median, 10 = after the blur, 11 = all
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float median25(float (&v)[25])
+{
+#define DCMT_CX(a, b)   { const float lo = fmin2(v[a], v[b]); v[b] = fmax2(v[a], v[b]); v[a] = lo; }
+#define DCMT_CMIN(a, b) { v[a] = fmin2(v[a], v[b]); }
+#define DCMT_CMAX(a, b) { v[b] = fmax2(v[a], v[b]); }
+    DCMT_MED25_NET(DCMT_CX, DCMT_CMIN, DCMT_CMAX)
+#undef DCMT_CX
+#undef DCMT_CMIN
+#undef DCMT_CMAX
+    return v[12];
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// which ping-pong buffer holds frame f after the loop applications that actually ran
+__device__ __forceinline__ int apps_done(const int* cnt, int n_apps_launched)
+{
+    int a = 0;
+    while (a < n_apps_launched && cnt[1 + a] > 0) ++a;   // application a+1 ran iff application a left holes
+    return a;
+}
+
+template <int TH, int TW>
+__global__ __launch_bounds__(kThreads)
+void k_post_v1(const float* __restrict__ pp0, const float* __restrict__ pp1, float* __restrict__ dst,
+               const int* __restrict__ counters, int n_apps_launched, int rows, int cols,
+               float max_depth, float thr, int blur, int mode)
+{
+    constexpr int R = 4, RH = TH + 2 * R, RW = TW + 2 * R, P = RW | 1;
+    __shared__ float A[RH * P];          // x, replicate-padded
+    __shared__ float B[RH * P];          // median
+    __shared__ float C[(TH + 4) * TW];   // horizontal Gaussian on rows tile-2 .. tile+2
+
+    const int f = blockIdx.z;
+    const int a = apps_done(counters + (size_t)f * kCntStride, n_apps_launched);
+    const size_t fo = (size_t)f * rows * cols;
+    const float* xin = ((a & 1) ? pp1 : pp0) + fo;
+    float* o = dst + fo;
+    const int ty0 = blockIdx.y * TH - R, tx0 = blockIdx.x * TW - R;
+
+    if (mode == 8) {
+        for_rect(0, TH, 0, TW, [&](int y, int x) {
+            const int gy = ty0 + R + y, gx = tx0 + R + x;
+            if (gy < rows && gx < cols) o[(size_t)gy * cols + gx] = xin[(size_t)gy * cols + gx];
+        });
+        return;
+    }
+    for_rect(0, RH, 0, RW, [&](int y, int x) {
+        const int gy = min(max(ty0 + y, 0), rows - 1), gx = min(max(tx0 + x, 0), cols - 1);
+        A[y * P + x] = xin[(size_t)gy * cols + gx];
+    });
+    __syncthreads();
+    // H9 on every in-image pixel of tile +- 2
+    for_rect(2, RH - 2, 2, RW - 2, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy < 0 || gy >= rows || gx < 0 || gx >= cols) return;
+        float v[25];
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) v[dy * 5 + dx] = A[(y + dy - 2) * P + x + dx - 2];
+        B[y * P + x] = median25(v);
+    });
+    __syncthreads();
+    const bool do_blur = blur == 1 && mode >= 10;
+    if (do_blur) {
+        // horizontal pass for the in-image rows of tile +- 2 (LO :179); reflect-101 in image coordinates
+        for_rect(2, RH - 2, R, RW - R, [&](int y, int x) {
+            const int gy = ty0 + y, gx = tx0 + x;
+            if (gy < 0 || gy >= rows || gx >= cols) return;
+            const float* b = B + y * P;
+            const float c0 = b[x];
+            const float l1 = b[reflect101(gx - 1, cols) - tx0], r1 = b[reflect101(gx + 1, cols) - tx0];
+            const float l2 = b[reflect101(gx - 2, cols) - tx0], r2 = b[reflect101(gx + 2, cols) - tx0];
+            float acc = __fmul_rn(c0, 0.375f);
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(l1, r1), 0.25f));
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(l2, r2), 0.0625f));
+            C[(y - 2) * TW + (x - R)] = acc;
+        });
+        __syncthreads();
+    }
+    for_rect(R, RH - R, R, RW - R, [&](int y, int x) {
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy >= rows || gx >= cols) return;
+        const float m = B[y * P + x];
+        float v = m;
+        if (do_blur) {
+            const int cx = x - R;
+            const int yu1 = reflect101(gy - 1, rows) - ty0 - 2, yd1 = reflect101(gy + 1, rows) - ty0 - 2;
+            const int yu2 = reflect101(gy - 2, rows) - ty0 - 2, yd2 = reflect101(gy + 2, rows) - ty0 - 2;
+            float acc = __fmul_rn(C[(y - 2) * TW + cx], 0.375f);
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(C[yu1 * TW + cx], C[yd1 * TW + cx]), 0.25f));
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(C[yu2 * TW + cx], C[yd2 * TW + cx]), 0.0625f));
+            if (m >= thr) v = acc;               // LO :184 `> 0.1`
+        }
+        if (mode >= 11) v = invert_valid(v, max_depth, thr);   // H11 (LO :191-202)
+        o[(size_t)gy * cols + gx] = v;
+    });
+}
+
+}  // namespace dcmt

@@ -1,0 +1,158 @@
+/*
+ * dcmt.h -- C ABI of the MI355X-native (gfx950 / CDNA4) morphological depth-completion
+ * cascade.  This is the drop-in boundary for the ONE hot path of
+ * PatrizioPerugini/depth_completion_MT:
+ *
+ *   void img_completion(const cv::Mat&, cv::Mat&, const bool&, const std::string&)
+ *        reference: src/DC_lidar_only/img_completion.cpp:17-20
+ *   void interpolate_with_superpixels(Slic&, const cv::Mat&, cv::Mat&, const std::string&, int)
+ *        reference: src/DC_lidar_camera/img_completion_lc.cpp:34-38
+ *
+ * The reference has no FFI or plugin registry: those two free-function signatures ARE the
+ * interface, and the header that declares them (img_completion.h) is missing from the
+ * reference repository.  include/img_completion.h in this repo is that header; it is a
+ * thin C++ shim over the entry points below (INTEGRATION.md shows the binding).
+ *
+ * Plain C: no C++ types, no exceptions, no torch types cross this boundary.  Every
+ * function returns DCMT_OK (0) or a negative dcmt_status.  A dcmt_ctx is bound to one
+ * GPU and owns all scratch memory; it must not be used from two threads at once (one ctx
+ * per GPU per host thread -- frames are independent, so multi-GPU is one ctx per device).
+ */
+#ifndef DCMT_H
+#define DCMT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCMT_VERSION 100 /* 0.1.0 */
+
+typedef struct dcmt_ctx dcmt_ctx;
+
+typedef enum {
+    DCMT_OK              = 0,
+    DCMT_E_INVALID       = -1, /* bad argument (null pointer, size beyond the ctx limits, empty k0) */
+    DCMT_E_UNSUPPORTED   = -2, /* blur == DCMT_BLUR_BILATERAL: the reference's call throws too (img_completion.cpp:174) */
+    DCMT_E_NOMEM         = -3, /* device or host allocation failed */
+    DCMT_E_HIP           = -4, /* a HIP runtime call failed; dcmt_last_hip_error() has the code */
+    DCMT_E_NOT_CONVERGED = -5, /* the hole-closure loop (img_completion.cpp:146-166) hit max_fill_iters with holes left */
+    DCMT_E_NO_DEVICE     = -6  /* no gfx950 device visible / wrong architecture */
+} dcmt_status;
+
+typedef enum {
+    DCMT_BLUR_NONE      = 0, /* any blur_type string other than the two below */
+    DCMT_BLUR_GAUSSIAN  = 1, /* "gaussian": GaussianBlur 5x5 sigma 0 + masked select (img_completion.cpp:176-189) */
+    DCMT_BLUR_BILATERAL = 2  /* "bilateral": rejected with DCMT_E_UNSUPPORTED */
+} dcmt_blur;
+
+/* Stages of the cascade, for `stop_after` (parity probes; 11 = the whole chain). */
+typedef enum {
+    DCMT_STAGE_INVERT   = 2,  /* img_completion.cpp:55-67   */
+    DCMT_STAGE_DILATE_K = 3,  /* :71-80   first dilate, element k0 */
+    DCMT_STAGE_CLOSE5   = 4,  /* :84-85   5x5 close (LC: the label-masked stage, img_completion_lc.cpp:78-102) */
+    DCMT_STAGE_FILL7    = 5,  /* :88-100  7x7 small-hole fill */
+    DCMT_STAGE_EXTEND   = 6,  /* :103-129 column extension */
+    DCMT_STAGE_FILL31   = 7,  /* :131-144 31x31 large-hole fill */
+    DCMT_STAGE_FILLLOOP = 8,  /* :146-166 repeat until no holes */
+    DCMT_STAGE_MEDIAN5  = 9,  /* :170     5x5 median */
+    DCMT_STAGE_BLUR     = 10, /* :172-189 blur + masked select */
+    DCMT_STAGE_FINAL    = 11  /* :191-202 invert back to metres */
+} dcmt_stage;
+
+/* All literals of the reference in one POD (SURVEY.md section 5 "Config / flags"). */
+typedef struct {
+    float   max_depth;       /* 100.0f                    img_completion.cpp:23 */
+    float   valid_thresh;    /* 0.1f: valid <=> x >= valid_thresh, hole <=> x < valid_thresh.
+                                The reference writes `depth > 0.1` / `depth < 0.1` against the DOUBLE
+                                literal; for f32 inputs that is exactly x >= 0.1f / x < 0.1f. */
+    uint8_t k0[25];          /* first structuring element, row-major 5x5, anchor centre, non-zero = tap.
+                                Default: what the reference COMPILES to (2 taps), see dcmt_k0_as_compiled. */
+    uint8_t _pad[3];
+    int32_t blur;            /* dcmt_blur */
+    int32_t max_fill_iters;  /* cap on the hole-closure loop (reference: unbounded); default 64 */
+    int32_t spec_fill_iters; /* device-pointer entry points only: how many loop applications are enqueued
+                                speculatively without a host round trip (each is skipped on the device for
+                                frames that have no holes left).  Default 1.  If a frame still has holes
+                                after them, dcmt_last_fill_iters() reports DCMT_E_NOT_CONVERGED for it. */
+    int32_t stop_after;      /* dcmt_stage; DCMT_STAGE_FINAL for the whole chain */
+    int32_t verbose;         /* 1: print what the reference prints (dims, hole counts) to stdout (host entry points) */
+} dcmt_params;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+
+/* Number of usable devices (0 if none); never fails. */
+int dcmt_device_count(void);
+
+/* Creates a context on `device` able to process up to max_batch frames of up to
+ * max_rows x max_cols per call.  Allocates all device scratch up front (about
+ * 12 B per pixel per frame of max_batch) so the call path never allocates. */
+int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx **out);
+void dcmt_destroy(dcmt_ctx *ctx);
+
+/* ---- parameters ------------------------------------------------------------------- */
+
+void dcmt_default_params(dcmt_params *p);
+/* The element the reference's `cv::Mat(5,5,CV_8UC1,d)` over `int d[5][5]` really is
+ * (img_completion.cpp:71-77): taps at (row 1,col 3) and (row 4,col 4) only. */
+void dcmt_k0_as_compiled(uint8_t k0[25]);
+/* The 13-tap radius-2 diamond the reference's comment intends. */
+void dcmt_k0_diamond(uint8_t k0[25]);
+
+/* ---- img_completion --------------------------------------------------------------- */
+
+/* HOST pointers, synchronous: copies in, runs the cascade, copies out.  Backs the cv::Mat
+ * shim (replaces the body of img_completion, img_completion.cpp:17-204).
+ * src/dst: f32, `batch` frames of rows x cols; row and frame strides in BYTES (cv::Mat::step
+ * for a single Mat; frame strides are ignored when batch == 1).  src is never written.
+ * The hole-closure loop runs exactly as many times as the reference would (up to
+ * max_fill_iters); returns DCMT_E_NOT_CONVERGED if the cap was hit (dst is still written). */
+int dcmt_complete_f32(dcmt_ctx *ctx,
+                      const float *src, size_t src_row_stride, size_t src_frame_stride,
+                      float *dst, size_t dst_row_stride, size_t dst_frame_stride,
+                      int rows, int cols, int batch, const dcmt_params *params);
+
+/* DEVICE pointers, stream-ordered, asynchronous: the measured path.  d_src/d_dst are
+ * contiguous [batch][rows][cols] f32 in device memory of ctx's GPU; `stream` is a
+ * hipStream_t (NULL = the default stream).  Never synchronises, never allocates. */
+int dcmt_complete_f32_dev(dcmt_ctx *ctx, const float *d_src, float *d_dst,
+                          int rows, int cols, int batch, const dcmt_params *params, void *stream);
+
+/* ---- interpolate_with_superpixels -------------------------------------------------- */
+
+/* As above with a label plane: int32 [rows][cols] ROW-MAJOR per frame (the reference keeps
+ * Slic::clusters[col][row]; the shim transposes), labels outside [0,n_labels) (e.g. -1)
+ * are not touched by the masked stage.  use_superpixel == 0 runs the unmasked first stage
+ * (img_completion_lc.cpp:59-64).  The Gaussian is applied whatever params->blur says, as in
+ * the reference (img_completion_lc.cpp:183 ignores blur_type). */
+int dcmt_complete_labeled_f32(dcmt_ctx *ctx,
+                              const float *src, size_t src_row_stride, size_t src_frame_stride,
+                              const int32_t *labels, size_t lab_row_stride, size_t lab_frame_stride,
+                              int n_labels,
+                              float *dst, size_t dst_row_stride, size_t dst_frame_stride,
+                              int rows, int cols, int batch, const dcmt_params *params,
+                              int use_superpixel);
+int dcmt_complete_labeled_f32_dev(dcmt_ctx *ctx, const float *d_src, const int32_t *d_labels,
+                                  int n_labels, float *d_dst, int rows, int cols, int batch,
+                                  const dcmt_params *params, int use_superpixel, void *stream);
+
+/* ---- probes ------------------------------------------------------------------------ */
+
+/* Per frame of the last call on ctx: the number of iterations the reference's while-loop
+ * (img_completion.cpp:146-166) ran (>= 1), i.e. the length of the hole-count sequence it
+ * prints.  Synchronises with the last call's stream.  out[i] = -1 for a frame that still
+ * had holes when the launches ran out (then the return value is DCMT_E_NOT_CONVERGED). */
+int dcmt_last_fill_iters(dcmt_ctx *ctx, int *out, int n);
+/* Per frame of the last call: holes seen by the first 31x31 fill (img_completion.cpp:131-144). */
+int dcmt_last_holes_after_extend(dcmt_ctx *ctx, int *out, int n);
+
+const char *dcmt_strerror(int status);
+int dcmt_last_hip_error(const dcmt_ctx *ctx);
+int dcmt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCMT_H */

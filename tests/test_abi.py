@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the C ABI library builds for gfx950, loads,
+exports every symbol include/dcmt.h declares, and the argument validation that needs no GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from depth_completion_mt_amd import _lib as L
+from depth_completion_mt_amd import api
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = L.build()
+    assert os.path.exists(path)
+    hdr = open(os.path.join(ROOT, "include", "dcmt.h")).read()
+    declared = set(re.findall(r"\b(dcmt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (dcmt_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    lib = L.lib()
+    for name in L.EXPORTS:
+        assert getattr(lib, name) is not None
+
+
+def test_code_object_targets_gfx950_only():
+    out = subprocess.run(["strings", "-n", "6", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    archs = set(re.findall(r"gfx[0-9a-f]{3,4}", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_params_struct_layout_matches_header():
+    assert ctypes.sizeof(L.Params) == 4 + 4 + 25 + 3 + 5 * 4
+    p = api.make_params()
+    assert p.max_depth == 100.0
+    assert np.float32(p.valid_thresh) == np.float32(0.1)
+    k = np.frombuffer(bytes(p.k0), dtype=np.uint8).reshape(5, 5)
+    want = np.zeros((5, 5), np.uint8)
+    want[1, 3] = want[4, 4] = 1
+    assert np.array_equal(k, want)                      # as-compiled element (img_completion.cpp:71-77)
+    assert p.blur == L.BLUR_GAUSSIAN and p.stop_after == L.STAGE_FINAL and p.max_fill_iters == 64
+    d = api.make_params(k0="diamond")
+    assert sum(bytes(d.k0)) == 13
+    assert api.make_params(blur_type="bilateral").blur == L.BLUR_BILATERAL
+    assert api.make_params(blur_type="whatever").blur == L.BLUR_NONE     # reference: any other string = no blur
+
+
+def test_status_strings_and_version():
+    assert L.lib().dcmt_version() == 100
+    for s in range(0, -7, -1):
+        assert L.strerror(s) and L.strerror(s) != "unknown status"
+    assert L.strerror(-99) == "unknown status"
+
+
+def test_null_and_range_validation_without_gpu():
+    lib = L.lib()
+    h = ctypes.c_void_p()
+    assert lib.dcmt_create(0, 0, 10, 1, ctypes.byref(h)) == L.E_INVALID
+    assert lib.dcmt_create(0, 10, 10, 1, None) == L.E_INVALID
+    p = api.make_params()
+    assert lib.dcmt_complete_f32_dev(None, None, None, 1, 1, 1, ctypes.byref(p), None) == L.E_INVALID
+    assert lib.dcmt_last_fill_iters(None, None, 0) == L.E_INVALID
+    lib.dcmt_destroy(None)      # no-op
+
+
+@pytest.mark.skipif(L.lib().dcmt_device_count() > 0, reason="a GPU is present")
+def test_product_path_fails_loudly_without_a_gpu():
+    """No CPU fallback: without a gfx950 device the product API raises."""
+    with pytest.raises(api.DcmtError) as e:
+        api.img_completion(np.zeros((8, 8), np.float32))
+    assert e.value.status == L.E_NO_DEVICE
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "depth_completion_mt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+\"dcmt_oracle", txt, re.M), f
+    for f in ("include/dcmt.h", "include/img_completion.h"):
+        pth = os.path.join(ROOT, f)
+        if os.path.exists(pth):
+            assert "dcmt_oracle" not in open(pth).read()

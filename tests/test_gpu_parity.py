@@ -1,0 +1,223 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle and the
+committed goldens.  Bit-exact for every stage (max/min/median/select are exact; the
+Gaussian uses the same operation order without FMA as the oracle).  Against another OpenCV
+build the Gaussian stage is a tolerance stage: |d| <= 1e-4."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from depth_completion_mt_amd import _lib as L
+from depth_completion_mt_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+GAUSS_TOL = 1e-4     # stated float tolerance of the Gaussian stage vs. any conforming OpenCV
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0, 400, 1300, 16)
+    yield c
+    c.close()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()
+
+
+def test_native_library_is_loaded():
+    assert L.lib().dcmt_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libdcmt_hip.so" in f.read()
+
+
+def test_per_stage_goldens(ctx, golden):
+    x = golden["crop48x64_in"]
+    for st in range(2, 12):
+        got = ctx.complete(x, api.make_params(stop_after=st))
+        assert_bit_equal(got, golden[f"crop48x64_stage{st}"], f"HIP stage {st}")
+    assert_bit_equal(ctx.complete(x, api.make_params(k0="diamond")), golden["crop48x64_diamond"], "diamond")
+    assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none")), golden["crop48x64_noblur"], "no blur")
+    assert_bit_equal(ctx.complete(golden["odd33x70_in"]), golden["odd33x70_out"], "33x70")
+    assert_bit_equal(ctx.complete(golden["odd33x70_in"], api.make_params(k0="diamond")), golden["odd33x70_diamond"], "33x70 diamond")
+
+
+def test_adversarial_goldens(ctx, golden, golden_meta):
+    for name, info in golden_meta["adversarial"].items():
+        x = golden[f"adv_{name}_in"]
+        got = ctx.complete(x, api.make_params(max_fill_iters=8), allow_not_converged=True)
+        assert_bit_equal(got, golden[f"adv_{name}_out"], f"adversarial {name}")
+        iters, st = ctx.last_fill_iters(1)
+        assert st == L.OK and iters[0] == info["fill_iters"], (name, iters, info)
+        assert ctx.last_holes_after_extend(1)[0] == info["holes_after_extend"], name
+
+
+def test_fill_loop_cap(ctx, golden, O):
+    x = golden["adv_tall_gap_in"]
+    got = ctx.complete(x, api.make_params(max_fill_iters=2), allow_not_converged=True)
+    assert ctx.last_status == L.E_NOT_CONVERGED
+    want = O.img_completion(x, O.default_params(max_fill_iters=2))
+    assert_bit_equal(got, want, "capped loop")
+    with pytest.raises(api.DcmtError):
+        ctx.complete(x, api.make_params(max_fill_iters=2))
+
+
+def test_stage_parity_full_size_vs_oracle(ctx, O, golden_meta):
+    for rows, cols, seed in [(352, 1216, 0), (375, 1242, 1)]:
+        x = synth.synth_frame(rows, cols, seed)
+        for st in (4, 5, 6, 7, 9, 11):
+            got = ctx.complete(x, api.make_params(stop_after=st))
+            want = O.img_completion(x, O.default_params(stop_after=st))
+            assert_bit_equal(got, want, f"{rows}x{cols} stage {st}")
+        m = golden_meta["full"][f"{rows}x{cols}_seed{seed}"]
+        assert sha(ctx.complete(x)) == m["out_sha256"]
+        assert ctx.last_fill_iters(1)[0][0] == m["fill_iters"]
+        assert ctx.last_holes_after_extend(1)[0] == m["holes_after_extend"]
+
+
+def test_gaussian_stage_within_stated_tolerance_of_fp64(ctx):
+    """The float stage against an fp64 evaluation of the same 5x5 binomial: the tolerance the
+    north star asks to be written down."""
+    x = synth.synth_frame(352, 1216, 5)
+    med = ctx.complete(x, api.make_params(stop_after=L.STAGE_MEDIAN5)).astype(np.float64)
+    blur = ctx.complete(x, api.make_params(stop_after=L.STAGE_BLUR)).astype(np.float64)
+    k = np.array([1, 4, 6, 4, 1], np.float64) / 16
+    p = np.pad(med, 2, mode="reflect")
+    t = sum(k[i] * p[:, i:i + med.shape[1]] for i in range(5))
+    g = sum(k[i] * t[i:i + med.shape[0], :] for i in range(5))
+    want = np.where(med >= np.float32(0.1), g, med)
+    assert np.abs(blur - want).max() <= GAUSS_TOL
+
+
+def test_device_entry_point_batch(ctx, O):
+    import torch
+    frames = synth.synth_batch(6, 352, 1216, 40)
+    frames[2] = 0                                   # an empty frame in the middle of the batch
+    frames[4, :, 100:140] = 0                       # empty columns
+    d = torch.from_numpy(frames).cuda()
+    out = ctx.complete_dev(d)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(frames.shape[0]):
+        assert_bit_equal(got[i], O.img_completion(frames[i]), f"device batch frame {i}")
+    iters, st = ctx.last_fill_iters(6)
+    assert st == L.OK and iters == [1] * 6
+    assert (got[2] == 0).all()
+    # a non-default stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out2 = ctx.complete_dev(d)
+    s.synchronize()
+    assert torch.equal(out, out2)
+    # frames are independent: a permuted batch gives permuted results
+    perm = [3, 0, 5, 1, 4, 2]
+    out3 = ctx.complete_dev(d[perm].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(out3, out[perm])
+
+
+def test_device_entry_point_speculative_loop(ctx, golden, O):
+    """tall_gap needs 7 loop iterations: with 1 speculative application the device path reports
+    non-convergence; with enough of them it matches the oracle."""
+    import torch
+    x = golden["adv_tall_gap_in"]
+    d = torch.from_numpy(x[None].copy()).cuda()
+    ctx.complete_dev(d, params=api.make_params(spec_fill_iters=1))
+    iters, st = ctx.last_fill_iters(1)
+    assert st == L.E_NOT_CONVERGED and iters == [-1]
+    out = ctx.complete_dev(d, params=api.make_params(spec_fill_iters=8))
+    iters, st = ctx.last_fill_iters(1)
+    assert st == L.OK and iters == [7]
+    assert_bit_equal(out.cpu().numpy()[0], O.img_completion(x), "speculative loop")
+
+
+def test_strided_host_input_and_output_independence(ctx, O):
+    big = np.zeros((60, 200), np.float32)
+    big[:, :] = -7.0
+    x = synth.synth_frame(60, 90, 9)
+    view = big[:, 50:140]
+    view[:] = x
+    assert view.strides[0] == 800
+    got = ctx.complete(view)
+    assert_bit_equal(got, O.img_completion(x), "strided input")
+    assert (big[:, :50] == -7).all() and (big[:, 140:] == -7).all()
+
+
+def test_labeled_variant(ctx, golden, golden_meta, O):
+    x, lab = golden["lc40x56_in"], golden["lc40x56_labels"]
+    nl = golden_meta["lc40x56_n_labels"]
+    got4 = ctx.complete(x, api.make_params(stop_after=L.STAGE_CLOSE5), labels=lab, n_labels=nl)
+    assert_bit_equal(got4, golden["lc40x56_stage4"], "LC stage 4")
+    assert_bit_equal(ctx.complete(x, labels=lab, n_labels=nl), golden["lc40x56_out"], "LC out")
+    assert_bit_equal(ctx.complete(x, labels=lab, n_labels=nl, use_superpixel=0), golden["lc40x56_out_nosp"], "LC nosp")
+    # blur_type is ignored by the reference's LC function: the Gaussian always runs
+    assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none"), labels=lab, n_labels=nl), golden["lc40x56_out"], "LC blur forced")
+    rng = np.random.default_rng(3)
+    lab2 = rng.integers(-1, 9, size=x.shape).astype(np.int32)
+    assert_bit_equal(ctx.complete(x, labels=lab2, n_labels=8), O.interpolate_with_superpixels(x, lab2, 8), "random labels")
+    # config 3 / 4 shapes
+    for rows, cols, nt, seed in [(352, 1216, 1200, 0), (375, 1242, 100, 2)]:
+        xf = synth.synth_frame(rows, cols, seed)
+        labf, nlf = synth.synth_labels(rows, cols, nt, seed)
+        got = ctx.complete(xf, labels=labf, n_labels=nlf)
+        assert_bit_equal(got, O.interpolate_with_superpixels(xf, labf, nlf), f"LC {rows}x{cols}")
+    m = golden_meta["full"]["lc_352x1216_seed0"]
+    labf, nlf = synth.synth_labels(352, 1216, 1200, 0)
+    assert sha(ctx.complete(synth.synth_frame(352, 1216, 0), labels=labf, n_labels=nlf)) == m["out_sha256"]
+
+
+def test_errors(ctx):
+    x = np.zeros((8, 8), np.float32)
+    with pytest.raises(api.DcmtError) as e:
+        ctx.complete(x, api.make_params(blur_type="bilateral"))
+    assert e.value.status == L.E_UNSUPPORTED        # the reference's bilateral call throws too
+    with pytest.raises(api.DcmtError) as e:
+        ctx.complete(np.zeros((401, 8), np.float32))
+    assert e.value.status == L.E_INVALID
+    p = api.make_params()
+    for i in range(25):
+        p.k0[i] = 0
+    with pytest.raises(api.DcmtError):
+        ctx.complete(x, p)
+
+
+def test_full_size_properties_large_batch():
+    """BASELINE sizes (a device-resident batch of 352x1216 frames), size-independent checks:
+    known answers for empty / single-pixel frames, per-frame independence, and the sha256 of
+    known frames inside a big batch."""
+    import torch
+    n = 96
+    with api.Context(0, 352, 1216, n) as c:
+        frames = synth.synth_batch(8, 352, 1216, 0)
+        big = np.concatenate([frames] * (n // 8))
+        big[17] = 0
+        big[33] = 0
+        big[33, 200, 600] = 10.0
+        d = torch.from_numpy(big).cuda()
+        out = c.complete_dev(d)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        iters, st = c.last_fill_iters(n)
+        assert st == L.OK and set(iters) == {1}
+        import json, os
+        from conftest import GOLDEN_DIR
+        meta = json.load(open(os.path.join(GOLDEN_DIR, "meta.json")))["full"]
+        assert sha(got[0]) == meta["352x1216_seed0"]["out_sha256"]
+        assert sha(got[1]) == meta["352x1216_seed1"]["out_sha256"]
+        assert sha(got[88]) == meta["352x1216_seed0"]["out_sha256"]
+        for i in range(8, n):
+            if i in (17, 33):
+                continue
+            assert np.array_equal(got[i], got[i % 8]), i          # same input, same output, anywhere in the batch
+        assert (got[17] == 0).all()                               # K1
+        assert set(np.unique(got[33]).tolist()) == {0.0, 0.625, 3.125, 6.875, 9.375, 10.0}   # K2
+        assert (got >= 0).all() and got.max() <= 100.0
