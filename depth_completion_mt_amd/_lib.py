@@ -57,11 +57,28 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, found through its RPATH); libdcmt_hip.so needs libamdhip64.so.7 too.  If
+    the system copy were loaded for us and the bundled one for torch, two HIP/HSA runtimes
+    would fight over the device ("No HIP GPUs are available").  Loading torch's copy first
+    makes the dynamic linker resolve our NEEDED entry to it by SONAME; a later `import torch`
+    finds the same file.  Without torch installed the system runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
         pp = ctypes.POINTER(Params)
