@@ -27,7 +27,7 @@ class DcmtError(RuntimeError):
 
 def make_params(k0="as_compiled", blur_type: str = "gaussian", stop_after: int = L.STAGE_FINAL,
                 max_fill_iters: int = 64, spec_fill_iters: int = 1, verbose: bool = False,
-                max_depth: float = 100.0, valid_thresh: float = 0.1) -> L.Params:
+                max_depth: float = 100.0, valid_thresh: float = 0.1, force_staged: bool = False) -> L.Params:
     p = L.Params()
     L.lib().dcmt_default_params(ctypes.byref(p))
     if isinstance(k0, str):
@@ -47,6 +47,7 @@ def make_params(k0="as_compiled", blur_type: str = "gaussian", stop_after: int =
     p.verbose = int(bool(verbose))
     p.max_depth = float(max_depth)
     p.valid_thresh = float(valid_thresh)
+    p.flags = L.FLAG_FORCE_STAGED if force_staged else 0
     return p
 
 
@@ -114,7 +115,7 @@ class Context:
         p = params or make_params()
         assert d_src.is_cuda and d_src.dtype == torch.float32 and d_src.is_contiguous()
         if d_dst is None:
-            d_dst = torch.empty_like(d_src)
+            d_dst = torch.full_like(d_src, float("nan"))     # never mistake stale memory for output
         assert d_dst.is_cuda and d_dst.dtype == torch.float32 and d_dst.is_contiguous() and d_dst.shape == d_src.shape
         shp = d_src.shape if d_src.dim() == 3 else (1,) + tuple(d_src.shape)
         b, r, c = shp

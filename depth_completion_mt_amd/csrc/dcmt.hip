@@ -14,6 +14,7 @@
 
 #include "dcmt.h"
 #include "dcmt_kernels_v1.h"
+#include "dcmt_kernels_fused.h"
 
 using namespace dcmt;
 
@@ -38,6 +39,7 @@ struct dcmt_ctx {
     int last_apps_launched = 0;       // loop applications (app >= 1) enqueued
     int last_has_loop = 0;            // the call went at least through H8
     int last_hip_error = 0;
+    int poison = 0;                   // env DCMT_POISON=1: fill the staging output with NaN before every host call
 };
 
 namespace {
@@ -76,6 +78,107 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
 
 dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
 
+using FillTile = FillT<59, 94>;     // 352 = 6 x 59 - 2, 1216 = 13 x 94 - 6: almost no tile waste at KITTI sizes
+
+int k0_preset(uint32_t kb)
+{
+    uint8_t k[25];
+    dcmt_k0_as_compiled(k);
+    if (kb == k0_bits(k)) return K0_AS_COMPILED;
+    dcmt_k0_diamond(k);
+    if (kb == k0_bits(k)) return K0_DIAMOND;
+    return -1;
+}
+
+// The hole-closure loop shared by both paths.  `launch_app(i)` enqueues application i
+// (reads pp[(i-1)&1], writes pp[i&1], skips frames without holes).  Returns the number of
+// applications enqueued through *apps.
+template <typename LaunchApp>
+int fill_loop(dcmt_ctx* ctx, int batch, const dcmt_params* p, hipStream_t st, bool sync_loop, LaunchApp launch_app, int* apps_out)
+{
+    int rc = DCMT_OK, apps = 0;
+    if (sync_loop) {
+        // Iteration i of the reference's loop (LO :146-166) counts the holes left by application
+        // i-1, fills them (application i: a no-op when there are none) and stops when it saw
+        // none; the cap bounds i.
+        for (int i = 1;; ++i) {
+            DCMT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(int) * (size_t)batch * kCntStride,
+                                         hipMemcpyDeviceToHost, st));
+            DCMT_HIP(ctx, hipStreamSynchronize(st));
+            bool any = false;
+            for (int f = 0; f < batch; ++f) {
+                const int n_i = ctx->h_counters[(size_t)f * kCntStride + i];   // [1 + (i-1)]
+                any |= n_i > 0;
+                if (p->verbose) std::printf("%d\n", n_i);                       // LO :161
+            }
+            if (!any) break;
+            launch_app(i);
+            DCMT_HIP(ctx, hipGetLastError());
+            apps = i;
+            if (i >= p->max_fill_iters) { rc = DCMT_E_NOT_CONVERGED; break; }
+        }
+    } else {
+        int n = p->spec_fill_iters;
+        if (n > p->max_fill_iters) n = p->max_fill_iters;
+        for (int i = 1; i <= n; ++i) launch_app(i);
+        apps = n;
+        DCMT_HIP(ctx, hipGetLastError());
+    }
+    *apps_out = apps;
+    return rc;
+}
+
+// Fast path: k_pre_s -> k_fill_t (-> k_fill_loop_t ...) -> k_post_s.  Preconditions checked by the caller.
+int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst, int rows, int cols, int batch,
+                    const dcmt_params* p, hipStream_t st, bool sync_loop)
+{
+    const int stop = p->stop_after;
+    ctx->last_stream = st;
+    ctx->last_batch = batch;
+    ctx->last_apps_launched = 0;
+    ctx->last_has_loop = 0;
+    DCMT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(int) * (size_t)batch * kCntStride, st));
+    {
+        float* x6 = stop == DCMT_STAGE_EXTEND ? d_dst : ctx->x5;
+        if (k0kind == K0_AS_COMPILED) {
+            const int strips = (cols + PreS<K0_AS_COMPILED>::VW - 1) / PreS<K0_AS_COMPILED>::VW;
+            hipLaunchKernelGGL((k_pre_s<K0_AS_COMPILED>), dim3((strips + 3) / 4, batch), dim3(256), 0, st, d_src, x6, rows, cols,
+                               strips, p->max_depth, p->valid_thresh);
+        } else {
+            const int strips = (cols + PreS<K0_DIAMOND>::VW - 1) / PreS<K0_DIAMOND>::VW;
+            hipLaunchKernelGGL((k_pre_s<K0_DIAMOND>), dim3((strips + 3) / 4, batch), dim3(256), 0, st, d_src, x6, rows, cols,
+                               strips, p->max_depth, p->valid_thresh);
+        }
+        DCMT_HIP(ctx, hipGetLastError());
+        if (stop == DCMT_STAGE_EXTEND) return DCMT_OK;
+    }
+    const dim3 fgrid((cols + FillTile::TW - 1) / FillTile::TW, (rows + FillTile::TH - 1) / FillTile::TH, batch);
+    hipLaunchKernelGGL((k_fill_t<FillTile>), fgrid, dim3(256), 0, st, ctx->x5, stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0],
+                       ctx->counters, rows, cols, p->valid_thresh);
+    DCMT_HIP(ctx, hipGetLastError());
+    if (stop == DCMT_STAGE_FILL31) return DCMT_OK;
+
+    ctx->last_has_loop = 1;
+    int apps = 0;
+    const int rc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
+        hipLaunchKernelGGL((k_fill_loop_t<FillTile>), dim3(batch), dim3(256), 0, st, ctx->pp[(i - 1) & 1], ctx->pp[i & 1],
+                           ctx->counters, rows, cols, p->valid_thresh, i);
+    }, &apps);
+    if (rc != DCMT_OK && rc != DCMT_E_NOT_CONVERGED) return rc;
+    ctx->last_apps_launched = apps;
+
+    if (stop <= DCMT_STAGE_FILLLOOP) {
+        hipLaunchKernelGGL((k_post_v1<TH, TW>), tile_grid(rows, cols, batch), dim3(kThreads), 0, st, ctx->pp[0], ctx->pp[1],
+                           d_dst, ctx->counters, apps, rows, cols, p->max_depth, p->valid_thresh, p->blur, 8);
+    } else {
+        const int strips = (cols + PostS::VW - 1) / PostS::VW;
+        hipLaunchKernelGGL(k_post_s, dim3((strips + 3) / 4, batch), dim3(256), 0, st, ctx->pp[0], ctx->pp[1], d_dst,
+                           ctx->counters, apps, rows, cols, strips, p->max_depth, p->valid_thresh, p->blur, stop);
+    }
+    DCMT_HIP(ctx, hipGetLastError());
+    return rc;
+}
+
 // Enqueues the cascade on `st`.  sync_loop: run the hole-closure loop exactly as the
 // reference would, reading the hole counters back between applications (host entry
 // points); otherwise enqueue p->spec_fill_iters applications speculatively.
@@ -87,6 +190,16 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     const uint32_t kb = k0_bits(p->k0);
     const int stop = p->stop_after;
     const int blur = force_gaussian ? (int)DCMT_BLUR_GAUSSIAN : p->blur;
+    {
+        const int kind = k0_preset(kb);
+        const bool labeled = d_labels && use_superpixel;
+        if (!(p->flags & DCMT_FLAG_FORCE_STAGED) && !labeled && kind >= 0 && rows >= 8 && cols >= 8 &&
+            stop >= DCMT_STAGE_EXTEND) {
+            dcmt_params q = *p;
+            q.blur = blur;
+            return run_chain_fused(ctx, kind, d_src, d_dst, rows, cols, batch, &q, st, sync_loop);
+        }
+    }
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_apps_launched = 0;
@@ -126,39 +239,12 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
 
     // H8
     ctx->last_has_loop = 1;
-    int rc = DCMT_OK;
     int apps = 0;
-    if (sync_loop) {
-        // Iteration i of the reference's loop (LO :146-166) counts the holes left by application
-        // i-1, fills them (application i: a no-op when there are none) and stops when it saw
-        // none; the cap bounds i.  Frames without holes skip an application on the device.
-        for (int i = 1;; ++i) {
-            DCMT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(int) * (size_t)batch * kCntStride,
-                                         hipMemcpyDeviceToHost, st));
-            DCMT_HIP(ctx, hipStreamSynchronize(st));
-            bool any = false;
-            for (int f = 0; f < batch; ++f) {
-                const int n_i = ctx->h_counters[(size_t)f * kCntStride + i];   // [1 + (i-1)]
-                any |= n_i > 0;
-                if (p->verbose) std::printf("%d\n", n_i);                       // LO :161
-            }
-            if (!any) break;
-            hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->pp[(i - 1) & 1], ctx->pp[i & 1],
-                               ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, i, 0);
-            DCMT_HIP(ctx, hipGetLastError());
-            apps = i;
-            if (i >= p->max_fill_iters) { rc = DCMT_E_NOT_CONVERGED; break; }
-        }
-    } else {
-        int n = p->spec_fill_iters;
-        if (n > p->max_fill_iters) n = p->max_fill_iters;
-        for (apps = 1; apps <= n; ++apps) {
-            hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->pp[(apps - 1) & 1], ctx->pp[apps & 1],
-                               ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, apps, 0);
-        }
-        apps = n;
-        DCMT_HIP(ctx, hipGetLastError());
-    }
+    const int rc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
+        hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->pp[(i - 1) & 1], ctx->pp[i & 1], ctx->colstat,
+                           ctx->counters, rows, cols, p->valid_thresh, i, 0);
+    }, &apps);
+    if (rc != DCMT_OK && rc != DCMT_E_NOT_CONVERGED) return rc;
     ctx->last_apps_launched = apps;
 
     const int mode = stop <= DCMT_STAGE_FILLLOOP ? 8 : stop;
@@ -199,6 +285,8 @@ int host_call(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int
             DCMT_HIP(ctx, hipMemcpy2DAsync((char*)ctx->d_lab + f * frame_b, row_b, (const char*)labels + f * lfs, lrs, row_b,
                                            rows, hipMemcpyHostToDevice, st));
     }
+    if (ctx->poison)   // DCMT_POISON=1: stale output can never pass for fresh output (tests)
+        DCMT_HIP(ctx, hipMemsetAsync(ctx->d_out, 0xFF, frame_b * (size_t)batch, st));
     const int chain_rc = run_chain(ctx, ctx->d_in, labels ? ctx->d_lab : nullptr, n_labels, use_superpixel, ctx->d_out,
                                    rows, cols, batch, p, force_gaussian, st, true);
     if (chain_rc != DCMT_OK && chain_rc != DCMT_E_NOT_CONVERGED) return chain_rc;
@@ -279,6 +367,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     ctx->device = device;
     ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
     ctx->frame_elems = (size_t)max_rows * max_cols;
+    { const char* e = std::getenv("DCMT_POISON"); ctx->poison = e && e[0] == '1'; }
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;

@@ -1,0 +1,433 @@
+// dcmt_kernels_fused.h -- the fast path for the default configuration (a preset first
+// element, the whole chain, images of at least 8x8): three launches per batch, the hot
+// stencils held entirely in registers.
+//
+//   k_pre_s   H2..H6   one wave64 owns a strip of columns over the FULL image height and
+//                      streams down the rows: lane = column, vertical windows live in
+//                      rolling registers, horizontal windows come from DPP wave shifts
+//                      (v_max_f32_dpp ... wave_shr:1 / wave_shl:1 -- no LDS, no barriers).
+//                      Because the wave sees whole columns, the column extension (H6) needs
+//                      no second kernel and no atomics: first/last valid row are tracked in
+//                      registers and the extension zones are written in the epilogue.
+//   k_fill_t   H7 (+H8) 31x31 dilate-fill on an LDS tile: the horizontal 31-max runs with
+//                      lane = row (a transposed walk over the odd-pitch tile), the vertical
+//                      one with lane = column; both are sliding maxima in registers.
+//   k_post_s  H9..H11  streaming like k_pre_s: 5x5 median from DPP-gathered neighbours,
+//                      separable Gaussian, masked select, final invert.
+//
+// Row indices in comments: i = input row of the current step; stage outputs lag behind.
+#pragma once
+
+#include "dcmt_kernels_v1.h"
+
+namespace dcmt {
+
+// value held by the lane to the left / right (column c-1 / c+1); lanes without a source
+// get 0 -- those are halo lanes whose results are never used.
+__device__ __forceinline__ float from_left(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_right(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return fmax2(fmax2(a, b), c); }   // -> v_max3_f32
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return fmin2(fmin2(a, b), c); }   // -> v_min3_f32
+
+// horizontal windows over lanes: 3 = [c-1,c+1], 5 = [c-2,c+2], 7 = [c-3,c+3]
+__device__ __forceinline__ float hmax3(float v) { const float a = fmax2(from_left(v), v); return fmax2(from_right(a), a); }
+__device__ __forceinline__ float hmin3(float v) { const float a = fmin2(from_left(v), v); return fmin2(from_right(a), a); }
+__device__ __forceinline__ float hgrow_max(float w) { const float l = from_left(w); return fmax2(from_right(w), l); }
+__device__ __forceinline__ float hgrow_min(float w) { const float l = from_left(w); return fmin2(from_right(w), l); }
+
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// k_pre_s
+// ---------------------------------------------------------------------------------
+enum { K0_AS_COMPILED = 0, K0_DIAMOND = 1 };
+
+template <int K0KIND>
+struct PreS {
+    // lanes lost to the left / right of a strip: the chain's horizontal reach.
+    // as-compiled element: taps (dy,dx) = (-1,+1),(+2,+2): reach 0 left, 2 right; diamond: 2 / 2.
+    static constexpr int HL = (K0KIND == K0_AS_COMPILED ? 0 : 2) + 2 + 2 + 3;
+    static constexpr int HR = 2 + 2 + 2 + 3;
+    static constexpr int VW = 64 - HL - HR;      // output columns per wave
+    static constexpr int LAT = 9;                // rows between the input row and the finished X5 row
+};
+
+template <int K0KIND>
+__global__ __launch_bounds__(256)
+void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, int cols, int strips,
+             float max_depth, float thr)
+{
+    using G = PreS<K0KIND>;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip >= strips) return;                 // whole waves leave; no barrier is used below
+    const int f = blockIdx.y;
+    const int gx = strip * G::VW - G::HL + lane;
+    const bool incol = gx >= 0 && gx < cols;
+    const bool outlane = incol && lane >= G::HL && lane < 64 - G::HR;
+    const size_t fo = (size_t)f * rows * cols;
+    const float* sp = src + fo + (incol ? gx : 0);
+    float* op = x6 + fo + (incol ? gx : 0);
+
+    constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
+    // rolling rows, indexed by (row & 7); fully unrolled below so every index is static
+    float PF[8];                                 // prefetched input rows
+    float XR[8];                                 // diamond only: x2 rows
+    float A3[8];                                 // diamond only: horizontal 3-max rows
+    float S1[8];                                 // as-compiled only: x2 shifted by one column
+    float H4[8], HE[8], H7[8], E4[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; H7[q] = NEG; E4[q] = NEG; PF[q] = 0.f; }
+
+    constexpr int PFD = 4;                       // rows of load lookahead
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) PF[q] = (incol && q < rows) ? sp[(size_t)q * cols] : 0.f;
+
+    int ti = -1, bi = -1;                        // first / last valid row of X5 in this lane's column
+    float tv = 0.f, bv = 0.f;
+
+    const int nsteps = rows + G::LAT;
+    for (int i0 = 0; i0 < nsteps; i0 += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int i = i0 + p;
+            // ---- H2 on load (LO :55-67); outside the image: the dilate border value
+            const float raw = PF[p];
+            PF[(p + PFD) & 7] = (incol && i + PFD < rows) ? sp[(size_t)(i + PFD) * cols] : 0.f;
+            const float x2 = (incol && i < rows) ? invert_valid(raw, max_depth, thr) : NEG;
+            // ---- H3 (LO :71-80), row j = i - 2
+            const int j = i - 2;
+            float y3;
+            if constexpr (K0KIND == K0_AS_COMPILED) {
+                // dst(r,c) = max(src(r-1,c+1), src(r+2,c+2))
+                const float s1 = from_right(x2);
+                const float s2 = from_right(s1);
+                S1[p] = s1;
+                y3 = fmax2(S1[(p + 5) & 7] /* row i-3 = j-1 */, s2 /* row i = j+2 */);
+            } else {
+                // 13-tap diamond: rows j-2 and j+2 centre only, j-1 and j+1 three wide, j five wide
+                const float a3 = hmax3(x2);
+                XR[p] = x2;
+                A3[p] = a3;
+                const float a3j = A3[(p + 6) & 7];                       // row j
+                const float a5j = hgrow_max(a3j);
+                y3 = fmax2(fmax3(XR[(p + 4) & 7] /* j-2 */, A3[(p + 5) & 7] /* j-1 */, a5j),
+                           fmax2(A3[(p + 7) & 7] /* j+1 */, x2 /* j+2 */));
+            }
+            y3 = (incol && (unsigned)j < (unsigned)rows) ? y3 : NEG;
+            // ---- H4 dilate 5x5 (LO :85): horizontal on row j, vertical gives row k = j - 2
+            H4[(p + 6) & 7] = hgrow_max(hmax3(y3));                      // slot of row j = i-2
+            const int k = i - 4;
+            float d4 = fmax3(fmax3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
+            d4 = (incol && (unsigned)k < (unsigned)rows) ? d4 : POS;     // border value of the erode
+            // ---- H4 erode 5x5: row l = k - 2
+            HE[(p + 4) & 7] = hgrow_min(hmin3(d4));                      // slot of row k = i-4
+            const int l = i - 6;
+            float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+            e4 = (incol && (unsigned)l < (unsigned)rows) ? e4 : NEG;     // border value of the 7x7 dilate
+            E4[(p + 2) & 7] = e4;                                        // slot of row l = i-6
+            // ---- H5 (LO :88-100): dilate 7x7, row m = l - 3, then fill where x < 0.1
+            H7[(p + 2) & 7] = hgrow_max(hgrow_max(hmax3(e4)));
+            const int m = i - 9;
+            const float d7 = fmax2(fmax3(fmax3(H7[(p + 4) & 7], H7[(p + 5) & 7], H7[(p + 6) & 7]),
+                                         H7[(p + 7) & 7], H7[(p + 0) & 7]),
+                                   fmax2(H7[(p + 1) & 7], H7[(p + 2) & 7]));   // rows m-3 .. m+3 = i-12 .. i-6
+            const float e = E4[(p + 7) & 7];                             // row m = i-9
+            const float x5 = e < thr ? d7 : e;
+            if ((unsigned)m < (unsigned)rows) {
+                // ---- H6 bookkeeping (LO :112-121): first / last row with x > 0.1
+                if (x5 >= thr) {
+                    if (ti < 0) { ti = m; tv = x5; }
+                    bi = m; bv = x5;
+                }
+                // rows above the first valid one are written by the epilogue
+                if (outlane && ti >= 0) op[(size_t)m * cols] = x5;
+            }
+        }
+    }
+    // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
+    // value; a column without valid pixels ends as 100 everywhere (:110, :125-127)
+    if (ti < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
+    if (!outlane) { ti = -1; bi = rows; }
+    const int tmax = wave_max_i(ti);
+    for (int r = 0; r <= tmax; ++r)
+        if (r <= ti) op[(size_t)r * cols] = tv;
+    const int bmin = wave_min_i(bi);
+    for (int r = bmin; r < rows; ++r)
+        if (r >= bi) op[(size_t)r * cols] = bv;
+}
+
+// ---------------------------------------------------------------------------------
+// k_post_s : H9 median 5x5 (replicate), H10 Gaussian (reflect-101) + select, H11 invert
+// mode: 9 = stop after the median, 10 = after the blur, 11 = everything
+// ---------------------------------------------------------------------------------
+struct PostS {
+    static constexpr int H = 4;                  // 2 (median) + 2 (Gaussian) lanes lost per side
+    static constexpr int VW = 64 - 2 * H;
+};
+
+__global__ __launch_bounds__(256)
+void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, float* __restrict__ dst,
+              const int* __restrict__ counters, int n_apps_launched, int rows, int cols, int strips,
+              float max_depth, float thr, int blur, int mode)
+{
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip >= strips) return;
+    const int f = blockIdx.y;
+    const int a = apps_done(counters + (size_t)f * kCntStride, n_apps_launched);
+    const size_t fo = (size_t)f * rows * cols;
+    const int gx0 = strip * PostS::VW - PostS::H;
+    const int gx = gx0 + lane;
+    const bool outlane = gx >= 0 && gx < cols && lane >= PostS::H && lane < 64 - PostS::H;
+    const int gxc = min(max(gx, 0), cols - 1);                       // BORDER_REPLICATE for the median
+    const float* sp = ((a & 1) ? pp1 : pp0) + fo + gxc;
+    float* op = dst + fo + gxc;
+    // reflect-101 source lane for the Gaussian's out-of-image columns (edge strips only)
+    const int rl = reflect101(gx, cols) - gx0;
+    const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
+    const bool do_blur = blur == 1 && mode >= 10;
+
+    // rolling rows indexed by (row mod 5) of the row they hold; 5-step unroll keeps indices static
+    float XC[5], XL1[5], XL2[5], XR1[5], XR2[5];  // input row and its 4 lane-shifted copies
+    float G1[5];                                  // horizontal Gaussian of median rows
+    float MR[5];                                  // median rows (centre values, for the select)
+    float PF[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { XC[q] = XL1[q] = XL2[q] = XR1[q] = XR2[q] = 0.f; G1[q] = 0.f; MR[q] = 0.f; PF[q] = 0.f; }
+    // stream rows v = -2 .. rows+1 (clamped): step t handles v = t - 2
+    constexpr int PFD = 3;
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - 2, 0), rows - 1) * cols];
+
+    const int nsteps = rows + 6;                 // the last output row o = t - 6 = rows - 1
+    for (int t0 = 0; t0 < nsteps; t0 += 5) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int t = t0 + p;
+            const int v = t - 2;                                       // (virtual) input row of this step
+            const float x = PF[p];
+            PF[(p + PFD) % 5] = sp[(size_t)min(max(t + PFD - 2, 0), rows - 1) * cols];
+            // slot of virtual row v: (v + 2) mod 5 = t mod 5 = p
+            XC[p] = x;
+            const float l1 = from_left(x), r1 = from_right(x);
+            XL1[p] = l1; XR1[p] = r1;
+            XL2[p] = from_left(l1); XR2[p] = from_right(r1);
+            // ---- H9 (LO :170): median of rows j-2..j+2, j = v - 2; slots p+1..p+5 (mod 5) = all five
+            const int j = v - 2;
+            float w[25];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { w[q * 5 + 0] = XL2[q]; w[q * 5 + 1] = XL1[q]; w[q * 5 + 2] = XC[q]; w[q * 5 + 3] = XR1[q]; w[q * 5 + 4] = XR2[q]; }
+            float m = median25(w);
+            // slot of row j for MR / G1: (j + 4) mod 5 = (t) mod 5 = p   (j + 4 = t)
+            if (mode == 9) {
+                if ((unsigned)j < (unsigned)rows && outlane) op[(size_t)j * cols] = m;
+                continue;
+            }
+            MR[p] = m;
+            // ---- H10 (LO :179): horizontal [1 4 6 4 1]/16 with reflect-101 columns
+            if (do_blur) {
+                float mf = m;
+                if (edge_strip) { const float mr = __shfl(m, rl, 64); mf = (gx < 0 || gx >= cols) ? mr : m; }
+                const float ml1 = from_left(mf), mr1 = from_right(mf);
+                const float ml2 = from_left(ml1), mr2 = from_right(mr1);
+                float acc = __fmul_rn(mf, 0.375f);
+                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml1, mr1), 0.25f));
+                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml2, mr2), 0.0625f));
+                G1[p] = acc;
+            }
+            // ---- vertical pass + select + invert for output row o = j - 2 (needs rows o-2..o+2 = .. j)
+            const int o = j - 2;
+            if ((unsigned)o < (unsigned)rows) {
+                // slots: row o+2 = j -> p, o+1 -> p+4, o -> p+3, o-1 -> p+2, o-2 -> p+1 (mod 5)
+                const float mo = MR[(p + 3) % 5];
+                float val = mo;
+                if (do_blur) {
+                    const float g_p2 = G1[p], g_p1 = G1[(p + 4) % 5], g_0 = G1[(p + 3) % 5], g_m1 = G1[(p + 2) % 5], g_m2 = G1[(p + 1) % 5];
+                    // reflect-101 rows (rows >= 8 is guaranteed by the dispatcher)
+                    const float u1 = o >= 1 ? g_m1 : g_p1;
+                    const float u2 = o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2);
+                    const float d1 = o + 1 < rows ? g_p1 : g_m1;
+                    const float d2 = o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2);
+                    float acc = __fmul_rn(g_0, 0.375f);
+                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
+                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
+                    if (mo >= thr) val = acc;                           // LO :184
+                }
+                if (mode >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
+                if (outlane) op[(size_t)o * cols] = val;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// k_fill_t : x = x < 0.1 ? dilate31(x) : x on an LDS tile (LO :131-144 and one iteration of
+// :146-166).  The 31-wide maxima are sliding maxima in registers over a fully unrolled
+// stream: w3 -> w9 -> w27 -> w31 (three v_max3 and one v_max per element).
+//   pass V (lane = column): streams DOWN the rows straight from global memory (coalesced
+//           rows), vertical 31-max -> LDS plane V [TH][RW]
+//   pass H (lane = row):    streams ALONG the columns of V (odd pitch: conflict-free),
+//           horizontal 31-max -> LDS plane D [TH][TW]
+//   select (lane = column): out = x < thr ? D : x, coalesced store, hole counts
+// ---------------------------------------------------------------------------------
+template <int TH_, int TW_>
+struct FillT {
+    static constexpr int TH = TH_, TW = TW_, R = 15;
+    static constexpr int RW = TW + 2 * R;          // input columns a tile needs
+    static constexpr int PV = RW | 1, PD = TW | 1; // odd pitches
+    static constexpr int LG = (RW + 63) / 64;      // lane groups of pass V
+    static constexpr int RP = 2;                   // row parts of pass V
+    static constexpr int NSV = (TH + RP - 1) / RP + 2 * R;   // steps of one pass-V task
+    static constexpr int RG = (TH + 63) / 64;      // row groups of pass H
+    static constexpr int SG = 4;                   // column segments of pass H
+    static constexpr int NSH = (TW + SG - 1) / SG + 2 * R;   // steps of one pass-H task
+    static constexpr int LDS_FLOATS = TH * PV + TH * PD;
+};
+
+// one sliding 31-max stream of N steps; get(s) supplies element s, put(s - 30, w) receives the
+// maximum of elements s-30..s for every s >= 30
+template <int N, typename Get, typename Put>
+__device__ __forceinline__ void sliding_max31(Get get, Put put)
+{
+    constexpr float NEG = -FLT_MAX;
+    float v[N], w3[N], w9[N], w27[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        v[s] = get(s);
+        w3[s] = fmax3(v[s], s >= 1 ? v[s - 1] : NEG, s >= 2 ? v[s - 2] : NEG);
+        w9[s] = fmax3(w3[s], s >= 3 ? w3[s - 3] : NEG, s >= 6 ? w3[s - 6] : NEG);
+        w27[s] = fmax3(w9[s], s >= 9 ? w9[s - 9] : NEG, s >= 18 ? w9[s - 18] : NEG);
+        if (s >= 30) put(s - 30, fmax2(w27[s], w27[s - 4]));
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void fill_tile(const float* __restrict__ xin, float* __restrict__ xout, float* lds,
+                                          int rows, int cols, int ty, int tx, float thr, int& before, int& after)
+{
+    constexpr float NEG = -FLT_MAX;
+    float* Vp = lds;
+    float* Dp = lds + T::TH * T::PV;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gy0 = ty * T::TH, gx0 = tx * T::TW;       // image coordinates of the tile origin
+
+    // pass V
+    for (int task = wave; task < T::LG * T::RP; task += 4) {
+        const int lg = task % T::LG, rp = task / T::LG;
+        const int x = lg * 64 + lane;                   // region column
+        const int gx = gx0 - T::R + x;
+        const bool act = x < T::RW;
+        const bool incol = act && gx >= 0 && gx < cols;
+        const int o0 = rp * T::TH / T::RP, o1 = (rp + 1) * T::TH / T::RP;   // output rows of this part
+        const float* colp = xin + (incol ? gx : 0);
+        sliding_max31<T::NSV>(
+            [&](int s) {
+                const int gy = gy0 - T::R + o0 + s;
+                return (incol && gy >= 0 && gy < rows && o0 + s < o1 + 2 * T::R) ? colp[(size_t)gy * cols] : NEG;
+            },
+            [&](int so, float w) {
+                if (act && o0 + so < o1) Vp[(o0 + so) * T::PV + x] = w;
+            });
+    }
+    __syncthreads();
+    // pass H
+    for (int task = wave; task < T::RG * T::SG; task += 4) {
+        const int rg = task % T::RG, sg = task / T::RG;
+        const int y = rg * 64 + lane;
+        const bool act = y < T::TH;
+        const int xo0 = sg * T::TW / T::SG, xo1 = (sg + 1) * T::TW / T::SG;
+        const float* rowp = Vp + (act ? y : 0) * T::PV;
+        sliding_max31<T::NSH>(
+            [&](int s) { return (xo0 + s < xo1 + 2 * T::R) ? rowp[xo0 + s] : NEG; },
+            [&](int so, float w) {
+                if (act && xo0 + so < xo1) Dp[y * T::PD + xo0 + so] = w;
+            });
+    }
+    __syncthreads();
+    // select + store + hole counts
+    for_rect(0, T::TH, 0, T::TW, [&](int y, int x) {
+        const int gy = gy0 + y, gx = gx0 + x;
+        if (gy >= rows || gx >= cols) return;
+        const float v = xin[(size_t)gy * cols + gx];
+        const bool hole = v < thr;                       // LO :140 / :154
+        const float o = hole ? Dp[y * T::PD + x] : v;
+        xout[(size_t)gy * cols + gx] = o;
+        before += hole;
+        after += o < thr;
+    });
+    __syncthreads();                                     // the planes are reused by the next tile (loop kernel)
+}
+
+__device__ __forceinline__ int block_sum(int v, int* s_tmp)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int r = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    __syncthreads();
+    return r;
+}
+
+// application 0 (H7) over the whole batch: grid (tiles_x, tiles_y, batch)
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_fill_t(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
+              int rows, int cols, float thr)
+{
+    __shared__ float lds[T::LDS_FLOATS];
+    __shared__ int s_tmp[4];
+    const int f = blockIdx.z;
+    const size_t fo = (size_t)f * rows * cols;
+    int before = 0, after = 0;
+    fill_tile<T>(in + fo, out + fo, lds, rows, cols, blockIdx.y, blockIdx.x, thr, before, after);
+    const int b = block_sum(before, s_tmp), a = block_sum(after, s_tmp);
+    if (threadIdx.x == 0) {
+        int* cnt = frame_counters(counters, f);
+        if (b) atomicAdd(&cnt[0], b);
+        if (a) atomicAdd(&cnt[1], a);
+    }
+}
+
+// application app >= 1 (one iteration of the H8 loop): one workgroup per frame; frames whose
+// previous application left no holes return at once (the common case), the others walk their
+// tiles.  An application without holes changes nothing, so skipping it is exact.
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_fill_loop_t(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
+                   int rows, int cols, float thr, int app)
+{
+    __shared__ float lds[T::LDS_FLOATS];
+    __shared__ int s_tmp[4];
+    const int f = blockIdx.x;
+    int* cnt = frame_counters(counters, f);
+    if (cnt[app] == 0) return;                           // holes left by application app-1
+    const size_t fo = (size_t)f * rows * cols;
+    const int tyn = (rows + T::TH - 1) / T::TH, txn = (cols + T::TW - 1) / T::TW;
+    int before = 0, after = 0;
+    for (int t = 0; t < tyn * txn; ++t)
+        fill_tile<T>(in + fo, out + fo, lds, rows, cols, t / txn, t % txn, thr, before, after);
+    const int a = block_sum(after, s_tmp);
+    if (threadIdx.x == 0) cnt[1 + app] = a;
+}
+
+}  // namespace dcmt

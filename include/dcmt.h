@@ -79,7 +79,12 @@ typedef struct {
                                 after them, dcmt_last_fill_iters() reports DCMT_E_NOT_CONVERGED for it. */
     int32_t stop_after;      /* dcmt_stage; DCMT_STAGE_FINAL for the whole chain */
     int32_t verbose;         /* 1: print what the reference prints (dims, hole counts) to stdout (host entry points) */
+    int32_t flags;           /* DCMT_FLAG_* */
 } dcmt_params;
+
+/* Use the general staged kernels even where the fused fast path applies (A/B tests, debugging).
+ * Both paths produce identical bits. */
+#define DCMT_FLAG_FORCE_STAGED 1
 
 /* ---- lifetime --------------------------------------------------------------------- */
 

@@ -34,7 +34,7 @@ def test_code_object_targets_gfx950_only():
 
 
 def test_params_struct_layout_matches_header():
-    assert ctypes.sizeof(L.Params) == 4 + 4 + 25 + 3 + 5 * 4
+    assert ctypes.sizeof(L.Params) == 4 + 4 + 25 + 3 + 6 * 4
     p = api.make_params()
     assert p.max_depth == 100.0
     assert np.float32(p.valid_thresh) == np.float32(0.1)
