@@ -172,8 +172,14 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                            d_dst, ctx->counters, apps, rows, cols, p->max_depth, p->valid_thresh, p->blur, 8);
     } else {
         const int strips = (cols + PostS::VW - 1) / PostS::VW;
-        hipLaunchKernelGGL(k_post_s, dim3((strips + 3) / 4, batch), dim3(256), 0, st, ctx->pp[0], ctx->pp[1], d_dst,
-                           ctx->counters, apps, rows, cols, strips, p->max_depth, p->valid_thresh, p->blur, stop);
+        const dim3 g((strips + 3) / 4, batch), b(256);
+        const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
+#define DCMT_POST(MODE, BLUR) hipLaunchKernelGGL((k_post_s<MODE, BLUR>), g, b, 0, st, ctx->pp[0], ctx->pp[1], d_dst, \
+                                                 ctx->counters, apps, rows, cols, strips, p->max_depth, p->valid_thresh)
+        if (stop == DCMT_STAGE_MEDIAN5) DCMT_POST(9, false);
+        else if (stop == DCMT_STAGE_BLUR) { if (bl) DCMT_POST(10, true); else DCMT_POST(10, false); }
+        else { if (bl) DCMT_POST(11, true); else DCMT_POST(11, false); }
+#undef DCMT_POST
     }
     DCMT_HIP(ctx, hipGetLastError());
     return rc;

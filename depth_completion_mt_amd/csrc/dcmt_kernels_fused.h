@@ -19,6 +19,7 @@
 #pragma once
 
 #include "dcmt_kernels_v1.h"
+#include "median_shared_nets.h"
 
 namespace dcmt {
 
@@ -76,15 +77,16 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
 {
     using G = PreS<K0KIND>;
     const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
     if (strip >= strips) return;                 // whole waves leave; no barrier is used below
     const int f = blockIdx.y;
     const int gx = strip * G::VW - G::HL + lane;
     const bool incol = gx >= 0 && gx < cols;
     const bool outlane = incol && lane >= G::HL && lane < 64 - G::HR;
     const size_t fo = (size_t)f * rows * cols;
-    const float* sp = src + fo + (incol ? gx : 0);
-    float* op = x6 + fo + (incol ? gx : 0);
+    const int gxc = min(max(gx, 0), cols - 1);       // loads are unconditional, from clamped addresses
+    const float* sp = src + fo + gxc;
+    float* op = x6 + fo + gxc;
 
     constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
     // rolling rows, indexed by (row & 7); fully unrolled below so every index is static
@@ -98,7 +100,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
 
     constexpr int PFD = 4;                       // rows of load lookahead
 #pragma unroll
-    for (int q = 0; q < PFD; ++q) PF[q] = (incol && q < rows) ? sp[(size_t)q * cols] : 0.f;
+    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(q, rows - 1) * cols];
 
     int ti = -1, bi = -1;                        // first / last valid row of X5 in this lane's column
     float tv = 0.f, bv = 0.f;
@@ -110,7 +112,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
             const int i = i0 + p;
             // ---- H2 on load (LO :55-67); outside the image: the dilate border value
             const float raw = PF[p];
-            PF[(p + PFD) & 7] = (incol && i + PFD < rows) ? sp[(size_t)(i + PFD) * cols] : 0.f;
+            PF[(p + PFD) & 7] = sp[(size_t)min(i + PFD, rows - 1) * cols];
             const float x2 = (incol && i < rows) ? invert_valid(raw, max_depth, thr) : NEG;
             // ---- H3 (LO :71-80), row j = i - 2
             const int j = i - 2;
@@ -177,19 +179,63 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
 // ---------------------------------------------------------------------------------
 // k_post_s : H9 median 5x5 (replicate), H10 Gaussian (reflect-101) + select, H11 invert
 // mode: 9 = stop after the median, 10 = after the blur, 11 = everything
+//
+// The exact median is time-shared down the column (tools/gen_median_shared.py has the scheme
+// and its verification): every row's 5 horizontal neighbours are sorted once (18 min/max),
+// every second row a pair of sorted rows is merged (26) and the six middle order statistics
+// of the 4-row core are extracted (36); each window's median is then the 6th smallest of
+// those six and the sorted fifth row (8).  57 min/max per pixel instead of ~200.
 // ---------------------------------------------------------------------------------
 struct PostS {
     static constexpr int H = 4;                  // 2 (median) + 2 (Gaussian) lanes lost per side
     static constexpr int VW = 64 - 2 * H;
 };
 
+#define DCMT_CX(a, b)   { const float lo_ = fmin2(v[a], v[b]); v[b] = fmax2(v[a], v[b]); v[a] = lo_; }
+#define DCMT_CMIN(a, b) { v[a] = fmin2(v[a], v[b]); }
+#define DCMT_CMAX(a, b) { v[b] = fmax2(v[a], v[b]); }
+__device__ __forceinline__ void sort5(float (&v)[5]) { DCMT_SORT5_NET(DCMT_CX, DCMT_CMIN, DCMT_CMAX) }
+// P = merge of two sorted 5-lists
+__device__ __forceinline__ void merge55(const float (&a)[5], const float (&b)[5], float (&P)[10])
+{
+    float v[10] = {a[0], a[1], a[2], a[3], a[4], b[0], b[1], b[2], b[3], b[4]};
+    DCMT_MERGE55_NET(DCMT_CX, DCMT_CMIN, DCMT_CMAX)
+    constexpr int out[10] = DCMT_MERGE55_OUT;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) P[k] = v[out[k]];
+}
+// C = ranks 8..13 (1-based, ascending) of the union of two sorted 10-lists
+__device__ __forceinline__ void mid20(const float (&pa)[10], const float (&pb)[10], float (&C)[6])
+{
+    float v[20];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { v[k] = pa[k]; v[10 + k] = pb[k]; }
+    DCMT_MID20_NET(DCMT_CX, DCMT_CMIN, DCMT_CMAX)
+    constexpr int out[6] = DCMT_MID20_OUT;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = v[out[k]];
+}
+#undef DCMT_CX
+#undef DCMT_CMIN
+#undef DCMT_CMAX
+// 6th smallest of sorted C (6) u sorted a (5) = the median of the 25-window
+__device__ __forceinline__ float final6(const float (&C)[6], const float (&a)[5])
+{
+    return fmin2(fmin3(C[5], fmax2(a[0], C[4]), fmax2(a[1], C[3])),
+                 fmin3(fmax2(a[2], C[2]), fmax2(a[3], C[1]), fmax2(a[4], C[0])));
+}
+
+// MODE (9/10/11) and BLUR are compile-time: a run-time branch around the ring updates would
+// make every join copy the rings (whole-array phis).
+template <int MODE, bool BLUR>
 __global__ __launch_bounds__(256)
 void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, float* __restrict__ dst,
               const int* __restrict__ counters, int n_apps_launched, int rows, int cols, int strips,
-              float max_depth, float thr, int blur, int mode)
+              float max_depth, float thr)
 {
+    constexpr int mode = MODE;
     const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
     if (strip >= strips) return;
     const int f = blockIdx.y;
     const int a = apps_done(counters + (size_t)f * kCntStride, n_apps_launched);
@@ -203,47 +249,69 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
     // reflect-101 source lane for the Gaussian's out-of-image columns (edge strips only)
     const int rl = reflect101(gx, cols) - gx0;
     const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
-    const bool do_blur = blur == 1 && mode >= 10;
+    constexpr bool do_blur = BLUR && MODE >= 10;
 
-    // rolling rows indexed by (row mod 5) of the row they hold; 5-step unroll keeps indices static
-    float XC[5], XL1[5], XL2[5], XR1[5], XR2[5];  // input row and its 4 lane-shifted copies
-    float G1[5];                                  // horizontal Gaussian of median rows
-    float MR[5];                                  // median rows (centre values, for the select)
-    float PF[5];
+    // Step t (= u) loads the replicate-clamped input row v = t - 2 and finishes the median of
+    // the window of rows u-4..u, i.e. the median at image row j = t - 4.
+    float SE[4][5];          // sorted even rows u = 2q, slot q & 3
+    float SO[5];             // the latest sorted odd row
+    float P[2][10];          // merged pairs (rows 2q-1, 2q), slot q & 1
+    float C[6];              // middle order statistics of the current 4-row core
+    float G1[8], MR[8];      // horizontal Gaussian / median rows, slot (image row) & 7
+    float PF[8];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { XC[q] = XL1[q] = XL2[q] = XR1[q] = XR2[q] = 0.f; G1[q] = 0.f; MR[q] = 0.f; PF[q] = 0.f; }
-    // stream rows v = -2 .. rows+1 (clamped): step t handles v = t - 2
-    constexpr int PFD = 3;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) SE[q][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) SO[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { P[0][k] = 0.f; P[1][k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { G1[q] = 0.f; MR[q] = 0.f; PF[q] = 0.f; }
+
+    constexpr int PFD = 4;
 #pragma unroll
     for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - 2, 0), rows - 1) * cols];
 
     const int nsteps = rows + 6;                 // the last output row o = t - 6 = rows - 1
-    for (int t0 = 0; t0 < nsteps; t0 += 5) {
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {
 #pragma unroll
-        for (int p = 0; p < 5; ++p) {
+        for (int p = 0; p < 8; ++p) {
             const int t = t0 + p;
-            const int v = t - 2;                                       // (virtual) input row of this step
             const float x = PF[p];
-            PF[(p + PFD) % 5] = sp[(size_t)min(max(t + PFD - 2, 0), rows - 1) * cols];
-            // slot of virtual row v: (v + 2) mod 5 = t mod 5 = p
-            XC[p] = x;
-            const float l1 = from_left(x), r1 = from_right(x);
-            XL1[p] = l1; XR1[p] = r1;
-            XL2[p] = from_left(l1); XR2[p] = from_right(r1);
-            // ---- H9 (LO :170): median of rows j-2..j+2, j = v - 2; slots p+1..p+5 (mod 5) = all five
-            const int j = v - 2;
-            float w[25];
+            PF[(p + PFD) & 7] = sp[(size_t)min(max(t + PFD - 2, 0), rows - 1) * cols];
+            // ---- H9 (LO :170)
+            float s[5];
+            {
+                const float l1 = from_left(x), r1 = from_right(x);
+                s[0] = from_left(l1); s[1] = l1; s[2] = x; s[3] = r1; s[4] = from_right(r1);
+            }
+            sort5(s);
+            float m;
+            if ((p & 1) == 0) {                                       // u = 2q
+                constexpr int dummy = 0; (void)dummy;
+                const int qs = (p >> 1) & 3;
+                merge55(SO, s, P[(p >> 1) & 1]);                      // rows u-1, u
+                mid20(P[((p >> 1) + 1) & 1], P[(p >> 1) & 1], C);     // core rows u-3 .. u
+                m = final6(C, SE[(qs + 2) & 3]);                      // + row u-4
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { w[q * 5 + 0] = XL2[q]; w[q * 5 + 1] = XL1[q]; w[q * 5 + 2] = XC[q]; w[q * 5 + 3] = XR1[q]; w[q * 5 + 4] = XR2[q]; }
-            float m = median25(w);
-            // slot of row j for MR / G1: (j + 4) mod 5 = (t) mod 5 = p   (j + 4 = t)
-            if (mode == 9) {
+                for (int k = 0; k < 5; ++k) SE[qs][k] = s[k];
+            } else {                                                  // u = 2q + 1
+                m = final6(C, s);                                     // core rows u-4 .. u-1, + row u
+#pragma unroll
+                for (int k = 0; k < 5; ++k) SO[k] = s[k];
+            }
+            const int j = t - 4;                                       // image row of this median
+            if constexpr (mode == 9) {
                 if ((unsigned)j < (unsigned)rows && outlane) op[(size_t)j * cols] = m;
                 continue;
             }
-            MR[p] = m;
+            MR[(p + 4) & 7] = m;
             // ---- H10 (LO :179): horizontal [1 4 6 4 1]/16 with reflect-101 columns
-            if (do_blur) {
+            if constexpr (do_blur) {
                 float mf = m;
                 if (edge_strip) { const float mr = __shfl(m, rl, 64); mf = (gx < 0 || gx >= cols) ? mr : m; }
                 const float ml1 = from_left(mf), mr1 = from_right(mf);
@@ -251,33 +319,35 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
                 float acc = __fmul_rn(mf, 0.375f);
                 acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml1, mr1), 0.25f));
                 acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml2, mr2), 0.0625f));
-                G1[p] = acc;
+                G1[(p + 4) & 7] = acc;
             }
-            // ---- vertical pass + select + invert for output row o = j - 2 (needs rows o-2..o+2 = .. j)
-            const int o = j - 2;
+            // ---- vertical pass + select + invert for output row o = j - 2 = t - 6
+            const int o = t - 6;
             if ((unsigned)o < (unsigned)rows) {
-                // slots: row o+2 = j -> p, o+1 -> p+4, o -> p+3, o-1 -> p+2, o-2 -> p+1 (mod 5)
-                const float mo = MR[(p + 3) % 5];
+                // slots: row o -> (p+2)&7, o+1 -> p+3, o+2 -> p+4, o-1 -> p+1, o-2 -> p
+                const float mo = MR[(p + 2) & 7];
                 float val = mo;
-                if (do_blur) {
-                    const float g_p2 = G1[p], g_p1 = G1[(p + 4) % 5], g_0 = G1[(p + 3) % 5], g_m1 = G1[(p + 2) % 5], g_m2 = G1[(p + 1) % 5];
-                    // reflect-101 rows (rows >= 8 is guaranteed by the dispatcher)
-                    const float u1 = o >= 1 ? g_m1 : g_p1;
-                    const float u2 = o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2);
-                    const float d1 = o + 1 < rows ? g_p1 : g_m1;
-                    const float d2 = o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2);
+                if constexpr (do_blur) {
+                    const float g_p2 = G1[(p + 4) & 7], g_p1 = G1[(p + 3) & 7], g_0 = G1[(p + 2) & 7];
+                    const float g_m1 = G1[(p + 1) & 7], g_m2 = G1[p];
+                    float u1 = g_m1, u2 = g_m2, d1 = g_p1, d2 = g_p2;
+                    if (o < 2 || o + 2 >= rows) {                        // reflect-101 rows (rows >= 8 guaranteed)
+                        u1 = o >= 1 ? g_m1 : g_p1;
+                        u2 = o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2);
+                        d1 = o + 1 < rows ? g_p1 : g_m1;
+                        d2 = o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2);
+                    }
                     float acc = __fmul_rn(g_0, 0.375f);
                     acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
                     acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
                     if (mo >= thr) val = acc;                           // LO :184
                 }
-                if (mode >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
+                if constexpr (mode >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
                 if (outlane) op[(size_t)o * cols] = val;
             }
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------
 // k_fill_t : x = x < 0.1 ? dilate31(x) : x on an LDS tile (LO :131-144 and one iteration of
@@ -324,10 +394,9 @@ template <typename T>
 __device__ __forceinline__ void fill_tile(const float* __restrict__ xin, float* __restrict__ xout, float* lds,
                                           int rows, int cols, int ty, int tx, float thr, int& before, int& after)
 {
-    constexpr float NEG = -FLT_MAX;
     float* Vp = lds;
     float* Dp = lds + T::TH * T::PV;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave id: scalar
     const int gy0 = ty * T::TH, gx0 = tx * T::TW;       // image coordinates of the tile origin
 
     // pass V
@@ -336,14 +405,15 @@ __device__ __forceinline__ void fill_tile(const float* __restrict__ xin, float* 
         const int x = lg * 64 + lane;                   // region column
         const int gx = gx0 - T::R + x;
         const bool act = x < T::RW;
-        const bool incol = act && gx >= 0 && gx < cols;
         const int o0 = rp * T::TH / T::RP, o1 = (rp + 1) * T::TH / T::RP;   // output rows of this part
-        const float* colp = xin + (incol ? gx : 0);
+        // Loads are unconditional, from addresses clamped into the image: a max filter whose
+        // centre is inside the image gives the same result with a replicated border as with the
+        // -FLT_MAX constant border (the border row/column is itself in the window), so neither
+        // rows nor columns need a sentinel select -- and a predicated load would make hipcc branch
+        // around every load and wait for each one in turn.
+        const float* colp = xin + min(max(gx, 0), cols - 1);
         sliding_max31<T::NSV>(
-            [&](int s) {
-                const int gy = gy0 - T::R + o0 + s;
-                return (incol && gy >= 0 && gy < rows && o0 + s < o1 + 2 * T::R) ? colp[(size_t)gy * cols] : NEG;
-            },
+            [&](int s) { return colp[(size_t)min(max(gy0 - T::R + o0 + s, 0), rows - 1) * cols]; },
             [&](int so, float w) {
                 if (act && o0 + so < o1) Vp[(o0 + so) * T::PV + x] = w;
             });
@@ -357,23 +427,38 @@ __device__ __forceinline__ void fill_tile(const float* __restrict__ xin, float* 
         const int xo0 = sg * T::TW / T::SG, xo1 = (sg + 1) * T::TW / T::SG;
         const float* rowp = Vp + (act ? y : 0) * T::PV;
         sliding_max31<T::NSH>(
-            [&](int s) { return (xo0 + s < xo1 + 2 * T::R) ? rowp[xo0 + s] : NEG; },
+            [&](int s) { return rowp[min(xo0 + s, T::RW - 1)]; },
             [&](int so, float w) {
                 if (act && xo0 + so < xo1) Dp[y * T::PD + xo0 + so] = w;
             });
     }
     __syncthreads();
     // select + store + hole counts
-    for_rect(0, T::TH, 0, T::TW, [&](int y, int x) {
-        const int gy = gy0 + y, gx = gx0 + x;
-        if (gy >= rows || gx >= cols) return;
-        const float v = xin[(size_t)gy * cols + gx];
-        const bool hole = v < thr;                       // LO :140 / :154
-        const float o = hole ? Dp[y * T::PD + x] : v;
-        xout[(size_t)gy * cols + gx] = o;
-        before += hole;
-        after += o < thr;
-    });
+    {
+        constexpr int NPX = T::TH * T::TW, NIT = (NPX + kThreads - 1) / kThreads;
+        float vin[NIT], vd[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {                  // all loads first, from clamped addresses
+            const int i = min((int)threadIdx.x + k * kThreads, NPX - 1);
+            const int y = i / T::TW, x = i - y * T::TW;
+            vin[k] = xin[(size_t)min(gy0 + y, rows - 1) * cols + min(gx0 + x, cols - 1)];
+            vd[k] = Dp[y * T::PD + x];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            const int y = i / T::TW, x = i - y * T::TW;
+            const int gy = gy0 + y, gx = gx0 + x;
+            if (i < NPX && gy < rows && gx < cols) {
+                const float v = vin[k];
+                const bool hole = v < thr;               // LO :140 / :154
+                const float o = hole ? vd[k] : v;
+                xout[(size_t)gy * cols + gx] = o;
+                before += hole;
+                after += o < thr;
+            }
+        }
+    }
     __syncthreads();                                     // the planes are reused by the next tile (loop kernel)
 }
 
