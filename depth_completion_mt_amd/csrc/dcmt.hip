@@ -40,6 +40,9 @@ struct dcmt_ctx {
     int last_has_loop = 0;            // the call went at least through H8
     int last_hip_error = 0;
     int poison = 0;                   // env DCMT_POISON=1: fill the staging output with NaN before every host call
+    int chunk = 0;                    // frames per chunk of the fused path (0 = whole batch); env DCMT_CHUNK
+    int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
+    int fill_cfg = 0;                 // 0: streaming k_fill_s (default); 1: LDS-tile k_fill_t; env DCMT_FILL_CFG
 };
 
 namespace {
@@ -78,7 +81,7 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
 
 dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
 
-using FillTile = FillT<59, 94>;     // 352 = 6 x 59 - 2, 1216 = 13 x 94 - 6: almost no tile waste at KITTI sizes
+using FillTile = FillT<30, 94>;     // LDS-tile variant of the 31x31 fill (env DCMT_FILL_CFG=1); the default is k_fill_s
 
 int k0_preset(uint32_t kb)
 {
@@ -129,6 +132,8 @@ int fill_loop(dcmt_ctx* ctx, int batch, const dcmt_params* p, hipStream_t st, bo
 }
 
 // Fast path: k_pre_s -> k_fill_t (-> k_fill_loop_t ...) -> k_post_s.  Preconditions checked by the caller.
+// The batch is walked in chunks of ctx->chunk frames so that a chunk's intermediates (X6, X7:
+// 2 x 1.7 MB per frame) stay resident in the 256 MiB Infinity Cache between the three kernels.
 int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst, int rows, int cols, int batch,
                     const dcmt_params* p, hipStream_t st, bool sync_loop)
 {
@@ -138,50 +143,76 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     ctx->last_apps_launched = 0;
     ctx->last_has_loop = 0;
     DCMT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(int) * (size_t)batch * kCntStride, st));
-    {
-        float* x6 = stop == DCMT_STAGE_EXTEND ? d_dst : ctx->x5;
-        if (k0kind == K0_AS_COMPILED) {
-            const int strips = (cols + PreS<K0_AS_COMPILED>::VW - 1) / PreS<K0_AS_COMPILED>::VW;
-            hipLaunchKernelGGL((k_pre_s<K0_AS_COMPILED>), dim3((strips + 3) / 4, batch), dim3(256), 0, st, d_src, x6, rows, cols,
-                               strips, p->max_depth, p->valid_thresh);
-        } else {
-            const int strips = (cols + PreS<K0_DIAMOND>::VW - 1) / PreS<K0_DIAMOND>::VW;
-            hipLaunchKernelGGL((k_pre_s<K0_DIAMOND>), dim3((strips + 3) / 4, batch), dim3(256), 0, st, d_src, x6, rows, cols,
-                               strips, p->max_depth, p->valid_thresh);
+    const size_t fe = (size_t)rows * cols;
+    const int chunk = (ctx->chunk > 0 && !sync_loop) ? ctx->chunk : batch;   // the host-synchronised loop works on the whole batch
+    const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
+    int rc = DCMT_OK, apps_all = 0;
+    for (int f0 = 0; f0 < batch; f0 += chunk) {
+        const int nb = batch - f0 < chunk ? batch - f0 : chunk;
+        const int xm = (ctx->xcd_map && nb % 8 == 0) ? 1 : 0;
+        const float* src = d_src + f0 * fe;
+        float* dst = d_dst + f0 * fe;
+        float* x6 = ctx->x5 + f0 * fe;
+        float* pp0 = ctx->pp[0] + f0 * fe;
+        float* pp1 = ctx->pp[1] + f0 * fe;
+        int* cnt = ctx->counters + (size_t)f0 * kCntStride;
+        {
+            float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
+            if (k0kind == K0_AS_COMPILED) {
+                const int strips = (cols + PreS<K0_AS_COMPILED>::VW - 1) / PreS<K0_AS_COMPILED>::VW;
+                hipLaunchKernelGGL((k_pre_s<K0_AS_COMPILED>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols,
+                                   strips, nb, xm, p->max_depth, p->valid_thresh);
+            } else {
+                const int strips = (cols + PreS<K0_DIAMOND>::VW - 1) / PreS<K0_DIAMOND>::VW;
+                hipLaunchKernelGGL((k_pre_s<K0_DIAMOND>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols,
+                                   strips, nb, xm, p->max_depth, p->valid_thresh);
+            }
+            DCMT_HIP(ctx, hipGetLastError());
+            if (stop == DCMT_STAGE_EXTEND) continue;
+        }
+        const int fstrips = (cols + FillS::VW - 1) / FillS::VW;
+        const dim3 fgrid(((fstrips + 3) / 4) * nb);
+        if (ctx->fill_cfg == 0) {
+            hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
+                               fstrips, nb, xm, p->valid_thresh, 0);
+        } else {   // LDS-tile variant (kept for A/B measurements)
+            const int tiles = ((cols + FillTile::TW - 1) / FillTile::TW) * ((rows + FillTile::TH - 1) / FillTile::TH);
+            hipLaunchKernelGGL((k_fill_t<FillTile>), dim3(tiles * nb), dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0,
+                               cnt, rows, cols, nb, xm, p->valid_thresh);
         }
         DCMT_HIP(ctx, hipGetLastError());
-        if (stop == DCMT_STAGE_EXTEND) return DCMT_OK;
-    }
-    const dim3 fgrid((cols + FillTile::TW - 1) / FillTile::TW, (rows + FillTile::TH - 1) / FillTile::TH, batch);
-    hipLaunchKernelGGL((k_fill_t<FillTile>), fgrid, dim3(256), 0, st, ctx->x5, stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0],
-                       ctx->counters, rows, cols, p->valid_thresh);
-    DCMT_HIP(ctx, hipGetLastError());
-    if (stop == DCMT_STAGE_FILL31) return DCMT_OK;
+        if (stop == DCMT_STAGE_FILL31) continue;
 
-    ctx->last_has_loop = 1;
-    int apps = 0;
-    const int rc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
-        hipLaunchKernelGGL((k_fill_loop_t<FillTile>), dim3(batch), dim3(256), 0, st, ctx->pp[(i - 1) & 1], ctx->pp[i & 1],
-                           ctx->counters, rows, cols, p->valid_thresh, i);
-    }, &apps);
-    if (rc != DCMT_OK && rc != DCMT_E_NOT_CONVERGED) return rc;
-    ctx->last_apps_launched = apps;
+        ctx->last_has_loop = 1;
+        int apps = 0;
+        const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
+            if (ctx->fill_cfg == 0)
+                hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
+                                   fstrips, nb, xm, p->valid_thresh, i);
+            else
+                hipLaunchKernelGGL((k_fill_loop_t<FillTile>), dim3(nb), dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0,
+                                   cnt, rows, cols, p->valid_thresh, i);
+        }, &apps);
+        if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
+        if (lrc != DCMT_OK) rc = lrc;
+        apps_all = apps;
 
-    if (stop <= DCMT_STAGE_FILLLOOP) {
-        hipLaunchKernelGGL((k_post_v1<TH, TW>), tile_grid(rows, cols, batch), dim3(kThreads), 0, st, ctx->pp[0], ctx->pp[1],
-                           d_dst, ctx->counters, apps, rows, cols, p->max_depth, p->valid_thresh, p->blur, 8);
-    } else {
-        const int strips = (cols + PostS::VW - 1) / PostS::VW;
-        const dim3 g((strips + 3) / 4, batch), b(256);
-        const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
-#define DCMT_POST(MODE, BLUR) hipLaunchKernelGGL((k_post_s<MODE, BLUR>), g, b, 0, st, ctx->pp[0], ctx->pp[1], d_dst, \
-                                                 ctx->counters, apps, rows, cols, strips, p->max_depth, p->valid_thresh)
-        if (stop == DCMT_STAGE_MEDIAN5) DCMT_POST(9, false);
-        else if (stop == DCMT_STAGE_BLUR) { if (bl) DCMT_POST(10, true); else DCMT_POST(10, false); }
-        else { if (bl) DCMT_POST(11, true); else DCMT_POST(11, false); }
+        if (stop <= DCMT_STAGE_FILLLOOP) {
+            hipLaunchKernelGGL((k_post_v1<TH, TW>), tile_grid(rows, cols, nb), dim3(kThreads), 0, st, pp0, pp1, dst, cnt, apps,
+                               rows, cols, p->max_depth, p->valid_thresh, p->blur, 8);
+        } else {
+            const int strips = (cols + PostS::VW - 1) / PostS::VW;
+            const dim3 g(((strips + 3) / 4) * nb), b(256);
+#define DCMT_POST(MODE, BLUR) hipLaunchKernelGGL((k_post_s<MODE, BLUR>), g, b, 0, st, pp0, pp1, dst, cnt, apps, rows, cols, strips, \
+                                                 nb, xm, p->max_depth, p->valid_thresh)
+            if (stop == DCMT_STAGE_MEDIAN5) DCMT_POST(9, false);
+            else if (stop == DCMT_STAGE_BLUR) { if (bl) DCMT_POST(10, true); else DCMT_POST(10, false); }
+            else { if (bl) DCMT_POST(11, true); else DCMT_POST(11, false); }
 #undef DCMT_POST
+        }
+        DCMT_HIP(ctx, hipGetLastError());
     }
-    DCMT_HIP(ctx, hipGetLastError());
+    ctx->last_apps_launched = apps_all;
     return rc;
 }
 
@@ -374,6 +405,9 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
     ctx->frame_elems = (size_t)max_rows * max_cols;
     { const char* e = std::getenv("DCMT_POISON"); ctx->poison = e && e[0] == '1'; }
+    { const char* e = std::getenv("DCMT_CHUNK"); if (e) ctx->chunk = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_XCD_MAP"); if (e) ctx->xcd_map = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_FILL_CFG"); if (e) ctx->fill_cfg = std::atoi(e); }
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;

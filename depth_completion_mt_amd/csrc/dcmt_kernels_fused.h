@@ -55,6 +55,25 @@ __device__ __forceinline__ int wave_min_i(int v)
     return v;
 }
 
+
+// Workgroup -> (frame, unit) mapping.  Workgroups are dealt round-robin over the 8 XCDs
+// (blocks b and b+8 share an XCD and its 4 MiB L2), so with xcd_map every XCD works through
+// whole frames: the units (strips / tiles) of one 1.7 MB frame run side by side on one XCD
+// and their overlapping halo reads hit that XCD's L2 instead of going out to HBM once per
+// XCD.  Placement only affects speed, never results.  units = units per frame.
+__device__ __forceinline__ void frame_unit(int b, int units, int batch, int xcd_map, int& f, int& u)
+{
+    if (xcd_map) {
+        const int xcd = b & 7, slot = b >> 3;
+        f = (slot / units) * 8 + xcd;
+        u = slot % units;
+    } else {
+        f = b / units;
+        u = b - f * units;
+    }
+    (void)batch;
+}
+
 // ---------------------------------------------------------------------------------
 // k_pre_s
 // ---------------------------------------------------------------------------------
@@ -73,13 +92,14 @@ struct PreS {
 template <int K0KIND>
 __global__ __launch_bounds__(256)
 void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, int cols, int strips,
-             float max_depth, float thr)
+             int batch, int xcd_map, float max_depth, float thr)
 {
     using G = PreS<K0KIND>;
     const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
+    int f, sg;
+    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
+    const int strip = sg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
     if (strip >= strips) return;                 // whole waves leave; no barrier is used below
-    const int f = blockIdx.y;
     const int gx = strip * G::VW - G::HL + lane;
     const bool incol = gx >= 0 && gx < cols;
     const bool outlane = incol && lane >= G::HL && lane < 64 - G::HR;
@@ -231,13 +251,14 @@ template <int MODE, bool BLUR>
 __global__ __launch_bounds__(256)
 void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, float* __restrict__ dst,
               const int* __restrict__ counters, int n_apps_launched, int rows, int cols, int strips,
-              float max_depth, float thr)
+              int batch, int xcd_map, float max_depth, float thr)
 {
     constexpr int mode = MODE;
     const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
+    int f, sg;
+    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
+    const int strip = sg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
     if (strip >= strips) return;
-    const int f = blockIdx.y;
     const int a = apps_done(counters + (size_t)f * kCntStride, n_apps_launched);
     const size_t fo = (size_t)f * rows * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
@@ -350,6 +371,119 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
 }
 
 // ---------------------------------------------------------------------------------
+// k_fill_s : x = x < 0.1 ? dilate31(x) : x, streaming like k_pre_s (LO :131-144 and one
+// iteration of :146-166).  One wave64 owns 64 columns over the full height.
+//   vertical 31-max:   doubling in rolling registers (w2, w4, w8, w16, then w16 + w16 shifted
+//                      by 15): 5 v_max per row, no redundancy (the strip is full height);
+//   horizontal 31-max: the wave's 64 lanes are four DPP rows of 16.  P / S = inclusive prefix /
+//                      suffix maxima inside each 16-lane row (4 + 4 v_max_f32_dpp row_shr/row_shl),
+//                      M = max(P, S) = the row's maximum.  A window [c-15, c+15] always covers
+//                      the whole 16-block of c, the tail of the block before it and the head
+//                      of the block after it:   out(c) = max(S(c-15), M(c), P(c+15)),
+//                      with the two neighbours fetched by ds_bpermute (no LDS storage).
+//                      34 of the 64 lanes (15..48) produce output.
+// A max filter centred inside the image gives the same result with replicated borders as with
+// the -FLT_MAX constant border, so all loads are simply clamped into the image: no masks.
+// app == 0: H7, counts the holes it sees (cnt[0]) and leaves (cnt[1]).
+// app >= 1: loop iteration; frames whose previous application left no holes return at once.
+// ---------------------------------------------------------------------------------
+struct FillS {
+    static constexpr int R = 15;
+    static constexpr int VW = 64 - 2 * R;        // 34 output columns per wave
+};
+
+// x = max(x, x shifted inside its 16-lane DPP row); lanes without a source keep x (bound_ctrl:0
+// disables them).  Written as in-place inline asm: hipcc cannot fold a "keep" DPP move into
+// v_max_f32 (it emits v_mov + v_mov_dpp + v_max), and it pads no hazards for asm, so the two
+// wait states between a VALU write of x and its DPP read are inside the string.
+#define DCMT_MAX_DPP(NAME, CTRL)                                                              \
+    __device__ __forceinline__ void NAME(float& x)                                            \
+    {                                                                                         \
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(x)); \
+    }
+DCMT_MAX_DPP(max_shr1, "row_shr:1") DCMT_MAX_DPP(max_shr2, "row_shr:2") DCMT_MAX_DPP(max_shr4, "row_shr:4") DCMT_MAX_DPP(max_shr8, "row_shr:8")
+DCMT_MAX_DPP(max_shl1, "row_shl:1") DCMT_MAX_DPP(max_shl2, "row_shl:2") DCMT_MAX_DPP(max_shl4, "row_shl:4") DCMT_MAX_DPP(max_shl8, "row_shl:8")
+#undef DCMT_MAX_DPP
+__device__ __forceinline__ float row_prefix_max(float x) { max_shr1(x); max_shr2(x); max_shr4(x); max_shr8(x); return x; }
+__device__ __forceinline__ float row_suffix_max(float x) { max_shl1(x); max_shl2(x); max_shl4(x); max_shl8(x); return x; }
+
+__global__ __launch_bounds__(256)
+void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
+              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app)
+{
+    const int lane = threadIdx.x & 63;
+    int f, sg;
+    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
+    const int strip = sg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (strip >= strips) return;
+    int* cnt = frame_counters(counters, f);
+    if (app >= 1 && cnt[app] == 0) return;       // holes left by application app-1: none
+    const int gx = strip * FillS::VW - FillS::R + lane;
+    const bool outlane = gx >= 0 && gx < cols && lane >= FillS::R && lane < 64 - FillS::R;
+    const size_t fo = (size_t)f * rows * cols;
+    const int gxc = min(max(gx, 0), cols - 1);
+    const float* sp = in + fo + gxc;
+    float* op = out + fo + gxc;
+    const int a_lo = ((lane - FillS::R) & 63) * 4, a_hi = ((lane + FillS::R) & 63) * 4;   // bpermute byte addresses
+
+    // rolling rows, slot = row & 15 (16-step unroll keeps every index static)
+    float PF[16], XC[16], W2[16], W4[16], W8[16], W16[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { PF[q] = 0.f; XC[q] = W2[q] = W4[q] = W8[q] = W16[q] = -FLT_MAX; }
+    // step t handles the (row-clamped) input row v = t - 15 and emits output row o = t - 30
+    constexpr int PFD = 8;
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - FillS::R, 0), rows - 1) * cols];
+    float vprev = -FLT_MAX;
+    int before = 0, after = 0;
+    const int nsteps = rows + 2 * FillS::R;
+    for (int t0 = 0; t0 < nsteps; t0 += 16) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int t = t0 + p;
+            const float x = PF[p];
+            PF[(p + PFD) & 15] = sp[(size_t)min(max(t + PFD - FillS::R, 0), rows - 1) * cols];
+            XC[p] = x;
+            // vertical: windows ending at row t of 2, 4, 8, 16, 31 rows
+            const float w2 = fmax2(x, vprev);
+            vprev = x;
+            W2[p] = w2;
+            const float w4 = fmax2(w2, W2[(p + 14) & 15]);          // t-2
+            W4[p] = w4;
+            const float w8 = fmax2(w4, W4[(p + 12) & 15]);          // t-4
+            W8[p] = w8;
+            const float w16 = fmax2(w8, W8[(p + 8) & 15]);          // t-8
+            const float w31 = fmax2(w16, W16[(p + 1) & 15]);        // t-15: rows t-30 .. t
+            W16[p] = w16;
+            // horizontal: columns c-15 .. c+15 of the vertical maxima
+            const float P = row_prefix_max(w31), S = row_suffix_max(w31);
+            const float s_lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_lo, __builtin_bit_cast(int, S)));
+            const float p_hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_hi, __builtin_bit_cast(int, P)));
+            const float d = fmax3(fmax2(P, S), s_lo, p_hi);
+            // output row o = t - 30; its own value sits 15 steps back
+            const int o = t - 2 * FillS::R;
+            if ((unsigned)o < (unsigned)rows) {
+                const float v = XC[(p + 1) & 15];                    // virtual row (t-15) - 15 ... see below
+                const bool hole = v < thr;                           // LO :140 / :154
+                const float r = hole ? d : v;
+                if (outlane) {
+                    op[(size_t)o * cols] = r;
+                    before += hole;
+                    after += r < thr;
+                }
+            }
+        }
+    }
+    // hole counts of this strip
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) { before += __shfl_xor(before, sh, 64); after += __shfl_xor(after, sh, 64); }
+    if (lane == 0) {
+        if (app == 0 && before) atomicAdd(&cnt[0], before);
+        if (after) atomicAdd(&cnt[1 + app], after);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // k_fill_t : x = x < 0.1 ? dilate31(x) : x on an LDS tile (LO :131-144 and one iteration of
 // :146-166).  The 31-wide maxima are sliding maxima in registers over a fully unrolled
 // stream: w3 -> w9 -> w27 -> w31 (three v_max3 and one v_max per element).
@@ -359,16 +493,16 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
 //           horizontal 31-max -> LDS plane D [TH][TW]
 //   select (lane = column): out = x < thr ? D : x, coalesced store, hole counts
 // ---------------------------------------------------------------------------------
-template <int TH_, int TW_>
+template <int TH_, int TW_, int RP_ = 2, int SG_ = 4>
 struct FillT {
     static constexpr int TH = TH_, TW = TW_, R = 15;
     static constexpr int RW = TW + 2 * R;          // input columns a tile needs
     static constexpr int PV = RW | 1, PD = TW | 1; // odd pitches
     static constexpr int LG = (RW + 63) / 64;      // lane groups of pass V
-    static constexpr int RP = 2;                   // row parts of pass V
+    static constexpr int RP = RP_;                 // row parts of pass V
     static constexpr int NSV = (TH + RP - 1) / RP + 2 * R;   // steps of one pass-V task
     static constexpr int RG = (TH + 63) / 64;      // row groups of pass H
-    static constexpr int SG = 4;                   // column segments of pass H
+    static constexpr int SG = SG_;                 // column segments of pass H
     static constexpr int NSH = (TW + SG - 1) / SG + 2 * R;   // steps of one pass-H task
     static constexpr int LDS_FLOATS = TH * PV + TH * PD;
 };
@@ -473,18 +607,20 @@ __device__ __forceinline__ int block_sum(int v, int* s_tmp)
     return r;
 }
 
-// application 0 (H7) over the whole batch: grid (tiles_x, tiles_y, batch)
+// application 0 (H7) over the whole batch: 1-D grid of batch * tiles workgroups (frame_unit mapping)
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_fill_t(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, float thr)
+              int rows, int cols, int batch, int xcd_map, float thr)
 {
     __shared__ float lds[T::LDS_FLOATS];
     __shared__ int s_tmp[4];
-    const int f = blockIdx.z;
+    const int txn = (cols + T::TW - 1) / T::TW, tyn = (rows + T::TH - 1) / T::TH;
+    int f, u;
+    frame_unit(blockIdx.x, txn * tyn, batch, xcd_map, f, u);
     const size_t fo = (size_t)f * rows * cols;
     int before = 0, after = 0;
-    fill_tile<T>(in + fo, out + fo, lds, rows, cols, blockIdx.y, blockIdx.x, thr, before, after);
+    fill_tile<T>(in + fo, out + fo, lds, rows, cols, u / txn, u % txn, thr, before, after);
     const int b = block_sum(before, s_tmp), a = block_sum(after, s_tmp);
     if (threadIdx.x == 0) {
         int* cnt = frame_counters(counters, f);
