@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -43,6 +44,7 @@ struct dcmt_ctx {
     int chunk = 0;                    // frames per chunk of the fused path (0 = whole batch); env DCMT_CHUNK
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
     int fill_cfg = 0;                 // 0: streaming k_fill_s (default); 1: LDS-tile k_fill_t; env DCMT_FILL_CFG
+    int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
 };
 
 namespace {
@@ -158,15 +160,14 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         int* cnt = ctx->counters + (size_t)f0 * kCntStride;
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
-            if (k0kind == K0_AS_COMPILED) {
-                const int strips = (cols + PreS<K0_AS_COMPILED>::VW - 1) / PreS<K0_AS_COMPILED>::VW;
-                hipLaunchKernelGGL((k_pre_s<K0_AS_COMPILED>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols,
-                                   strips, nb, xm, p->max_depth, p->valid_thresh);
-            } else {
-                const int strips = (cols + PreS<K0_DIAMOND>::VW - 1) / PreS<K0_DIAMOND>::VW;
-                hipLaunchKernelGGL((k_pre_s<K0_DIAMOND>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols,
-                                   strips, nb, xm, p->max_depth, p->valid_thresh);
-            }
+            // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
+            const bool wide = ctx->wide && cols % 4 == 0 && ((uintptr_t)src % 16 == 0);
+#define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
+                hipLaunchKernelGGL((k_pre_s<KIND, WIDE>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols, \
+                                   strips, nb, xm, p->max_depth, p->valid_thresh); }
+            if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
+            else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
+#undef DCMT_PRE
             DCMT_HIP(ctx, hipGetLastError());
             if (stop == DCMT_STAGE_EXTEND) continue;
         }
@@ -408,6 +409,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_CHUNK"); if (e) ctx->chunk = std::atoi(e); }
     { const char* e = std::getenv("DCMT_XCD_MAP"); if (e) ctx->xcd_map = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FILL_CFG"); if (e) ctx->fill_cfg = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;

@@ -75,26 +75,70 @@ __device__ __forceinline__ void frame_unit(int b, int units, int batch, int xcd_
 }
 
 // ---------------------------------------------------------------------------------
+// RowRing: wave-private LDS ring filled by LDS-DMA.  One global_load_lds_dwordx4 moves a 4-row
+// x 64-column block (64 lanes x 16 B, the widest access) for the wave's strip straight into
+// LDS -- no VGPRs, asynchronous -- and every row is then one conflict-free ds_read_b32 per
+// lane.  Measured on MI355X (tools/bw_probe.hip): the one-dword-per-lane row loads of a strip
+// kernel stream at 4.0 TB/s, this form at 4.7 TB/s = the plain float4-copy rate of the box.
+// Requirements (checked by the dispatcher): cols % 4 == 0 and the strip origin gx0 % 4 == 0,
+// so every lane's 16-byte source is aligned and never straddles the image edge.
+// Stream row s (s = 0, 1, ...) is image row clamp(s - ROW_OFF): replicated rows for free.
+// Column groups outside the image are clamped as a group: they deliver in-image substitutes
+// from the 4 edge columns (fine for masked or max-filtered halos; k_post_s patches its lanes).
+// The ring belongs to ONE wave: its own counted vmcnt is all the ordering the reads need.
+// ---------------------------------------------------------------------------------
+template <int SLOTS, int ROW_OFF>
+struct RowRing {
+    float* ring;            // SLOTS x 256 floats, this wave's
+    const float* src;       // frame base + clamped group column of this lane
+    int rows, cols, lrow;
+
+    __device__ __forceinline__ void init(float* wave_ring, const float* frame, int rows_, int cols_, int gx0, int lane)
+    {
+        ring = wave_ring; rows = rows_; cols = cols_;
+        lrow = lane >> 4;
+        src = frame + min(max(gx0 + 4 * (lane & 15), 0), cols_ - 4);
+    }
+    // stream rows 4*chunk .. 4*chunk+3  ->  ring slot chunk % SLOTS
+    __device__ __forceinline__ void issue(int chunk) const
+    {
+        const int r = min(max(4 * chunk + lrow - ROW_OFF, 0), rows - 1);
+        const float* g = src + (size_t)r * cols;
+        float* l = ring + (chunk % SLOTS) * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    // all but the `keep` youngest DMAs of this wave have landed (stores issued in between only make
+    // the wait stricter: vmcnt counts loads and stores together, in order)
+    template <int KEEP>
+    __device__ __forceinline__ void wait() const { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); }
+    __device__ __forceinline__ float read(int s, int lane) const { return ring[((s >> 2) % SLOTS) * 256 + (s & 3) * 64 + lane]; }
+};
+
+// ---------------------------------------------------------------------------------
 // k_pre_s
 // ---------------------------------------------------------------------------------
 enum { K0_AS_COMPILED = 0, K0_DIAMOND = 1 };
 
-template <int K0KIND>
+template <int K0KIND, bool WIDE = false>
 struct PreS {
     // lanes lost to the left / right of a strip: the chain's horizontal reach.
     // as-compiled element: taps (dy,dx) = (-1,+1),(+2,+2): reach 0 left, 2 right; diamond: 2 / 2.
-    static constexpr int HL = (K0KIND == K0_AS_COMPILED ? 0 : 2) + 2 + 2 + 3;
+    // WIDE (LDS-DMA rows): the strip origin must be a multiple of 4 columns: HL rounded up to 8/12, VW to 48/44.
+    static constexpr int HL0 = (K0KIND == K0_AS_COMPILED ? 0 : 2) + 2 + 2 + 3;
+    static constexpr int HL = WIDE ? (HL0 + 3) / 4 * 4 : HL0;
     static constexpr int HR = 2 + 2 + 2 + 3;
-    static constexpr int VW = 64 - HL - HR;      // output columns per wave
+    static constexpr int VW = WIDE ? (64 - HL - HR) / 4 * 4 : 64 - HL - HR;   // output columns per wave
     static constexpr int LAT = 9;                // rows between the input row and the finished X5 row
 };
 
-template <int K0KIND>
+template <int K0KIND, bool WIDE>
 __global__ __launch_bounds__(256)
 void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, int cols, int strips,
              int batch, int xcd_map, float max_depth, float thr)
 {
-    using G = PreS<K0KIND>;
+    using G = PreS<K0KIND, WIDE>;
+    __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * 4 * 256 : 4];   // 4 waves x 4 slots x (4 rows x 64 columns)
     const int lane = threadIdx.x & 63;
     int f, sg;
     frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
@@ -102,11 +146,13 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
     if (strip >= strips) return;                 // whole waves leave; no barrier is used below
     const int gx = strip * G::VW - G::HL + lane;
     const bool incol = gx >= 0 && gx < cols;
-    const bool outlane = incol && lane >= G::HL && lane < 64 - G::HR;
+    const bool outlane = incol && lane >= G::HL && lane < G::HL + G::VW;
     const size_t fo = (size_t)f * rows * cols;
     const int gxc = min(max(gx, 0), cols - 1);       // loads are unconditional, from clamped addresses
     const float* sp = src + fo + gxc;
     float* op = x6 + fo + gxc;
+    RowRing<4, 0> rr;
+    if constexpr (WIDE) rr.init(s_ring + (strip & 3) * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
 
     constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
     // rolling rows, indexed by (row & 7); fully unrolled below so every index is static
@@ -119,8 +165,12 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
     for (int q = 0; q < 8; ++q) { XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; H7[q] = NEG; E4[q] = NEG; PF[q] = 0.f; }
 
     constexpr int PFD = 4;                       // rows of load lookahead
+    if constexpr (WIDE) {
+        rr.issue(0); rr.issue(1); rr.issue(2);   // three 4-row blocks ahead
+    } else {
 #pragma unroll
-    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(q, rows - 1) * cols];
+        for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(q, rows - 1) * cols];
+    }
 
     int ti = -1, bi = -1;                        // first / last valid row of X5 in this lane's column
     float tv = 0.f, bv = 0.f;
@@ -131,8 +181,14 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
         for (int p = 0; p < 8; ++p) {
             const int i = i0 + p;
             // ---- H2 on load (LO :55-67); outside the image: the dilate border value
-            const float raw = PF[p];
-            PF[(p + PFD) & 7] = sp[(size_t)min(i + PFD, rows - 1) * cols];
+            float raw;
+            if constexpr (WIDE) {
+                if ((p & 3) == 0) { rr.issue((i >> 2) + 3); rr.template wait<3>(); }
+                raw = rr.read(i, lane);
+            } else {
+                raw = PF[p];
+                PF[(p + PFD) & 7] = sp[(size_t)min(i + PFD, rows - 1) * cols];
+            }
             const float x2 = (incol && i < rows) ? invert_valid(raw, max_depth, thr) : NEG;
             // ---- H3 (LO :71-80), row j = i - 2
             const int j = i - 2;
