@@ -1,0 +1,65 @@
+// Exercises include/img_completion.h exactly as the reference's main.cpp calls it
+// (src/DC_lidar_only/main.cpp:93: img_completion(sparse, dense, false, "gaussian")) and as
+// main_lc.cpp:220 calls interpolate_with_superpixels.  Reads raw f32/int32 files written by the
+// pytest driver, writes raw f32 results; the driver compares them with the oracle.
+//   shim_test <rows> <cols> <in.f32> <out.f32> [labels.i32 n_labels out_lc.f32]
+#include "img_completion.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+static bool read_all(const char* path, void* dst, size_t bytes)
+{
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    const size_t n = std::fread(dst, 1, bytes, f);
+    std::fclose(f);
+    return n == bytes;
+}
+static bool write_all(const char* path, const void* src, size_t bytes)
+{
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return false;
+    const size_t n = std::fwrite(src, 1, bytes, f);
+    std::fclose(f);
+    return n == bytes;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 5) return 2;
+    const int rows = std::atoi(argv[1]), cols = std::atoi(argv[2]);
+    // a strided input (row step > cols * 4), as a ROI of a bigger cv::Mat would be
+    const size_t pad = 16, row_step = (size_t)(cols + pad) * sizeof(float);
+    std::vector<float> storage((size_t)rows * (cols + pad), -7.0f), packed((size_t)rows * cols);
+    if (!read_all(argv[3], packed.data(), packed.size() * 4)) return 3;
+    for (int r = 0; r < rows; ++r) std::memcpy(&storage[(size_t)r * (cols + pad)], &packed[(size_t)r * cols], (size_t)cols * 4);
+    cv::Mat sparse(rows, cols, CV_32FC1, storage.data(), row_step);
+    cv::Mat dense;                                   // empty, as in the reference's main (main.cpp:89)
+    img_completion(sparse, dense, false, "gaussian");
+    if (dense.rows != rows || dense.cols != cols || dense.type() != CV_32FC1) return 4;
+    std::vector<float> out((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], dense.ptr<float>(r), (size_t)cols * 4);
+    if (!write_all(argv[4], out.data(), out.size() * 4)) return 5;
+    for (int r = 0; r < rows; ++r)                    // the input must be untouched (const&)
+        if (std::memcmp(&storage[(size_t)r * (cols + pad)], &packed[(size_t)r * cols], (size_t)cols * 4) != 0) return 6;
+
+    bool threw = false;                               // "bilateral" throws in the reference (in-place cv::bilateralFilter)
+    try { img_completion(sparse, dense, false, "bilateral"); } catch (const std::exception&) { threw = true; }
+    if (!threw) return 7;
+
+    if (argc >= 8) {
+        const int n_labels = std::atoi(argv[6]);
+        std::vector<int32_t> lab((size_t)rows * cols);
+        if (!read_all(argv[5], lab.data(), lab.size() * 4)) return 8;
+        std::vector<std::vector<int> > clusters(cols, std::vector<int>(rows));   // [col][row], as Slic::clusters
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) clusters[c][r] = lab[(size_t)r * cols + c];
+        cv::Mat dense_sp;
+        dcmt_shim::interpolate_with_labels(clusters, n_labels, sparse, dense_sp, "gaussian", 1);
+        for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], dense_sp.ptr<float>(r), (size_t)cols * 4);
+        if (!write_all(argv[7], out.data(), out.size() * 4)) return 9;
+    }
+    std::printf("shim ok\n");
+    return 0;
+}

@@ -221,3 +221,33 @@ def test_full_size_properties_large_batch():
         assert (got[17] == 0).all()                               # K1
         assert set(np.unique(got[33]).tolist()) == {0.0, 0.625, 3.125, 6.875, 9.375, 10.0}   # K2
         assert (got >= 0).all() and got.max() <= 100.0
+
+
+def test_fused_path_odd_sizes_and_presets(ctx, O):
+    """The fused streaming kernels against the oracle on awkward geometries (strip / chunk tails,
+    images narrower than a strip, the smallest sizes the fused path accepts) and both k0 presets;
+    and the staged kernels forced on the same inputs."""
+    rng = np.random.default_rng(11)
+    for rows, cols in [(8, 8), (9, 200), (100, 8), (65, 129), (31, 47), (64, 48), (17, 1216), (352, 60), (128, 132)]:
+        x = synth.synth_frame(rows, cols, rows * 1000 + cols)
+        x[rng.integers(0, rows, 5), rng.integers(0, cols, 5)] = 30.0      # something valid even in tiny frames
+        for k0 in ("as_compiled", "diamond"):
+            want = O.img_completion(x, O.default_params(k0=k0))
+            assert_bit_equal(ctx.complete(x, api.make_params(k0=k0)), want, f"fused {rows}x{cols} {k0}")
+            assert_bit_equal(ctx.complete(x, api.make_params(k0=k0, force_staged=True)), want, f"staged {rows}x{cols} {k0}")
+    x = synth.synth_frame(352, 1216, 77)
+    assert_bit_equal(ctx.complete(x, api.make_params(k0="diamond")), O.img_completion(x, O.default_params(k0="diamond")), "diamond full size")
+    assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none")), O.img_completion(x, O.default_params(blur="none")), "no blur full size")
+    for st in (6, 7, 8, 9, 10):
+        assert_bit_equal(ctx.complete(x, api.make_params(stop_after=st)), O.img_completion(x, O.default_params(stop_after=st)), f"fused stage {st}")
+
+
+def test_dense_and_adversarial_values_full_size(ctx, O):
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0.0, 130.0, size=(352, 1216)).astype(np.float32)     # dense, incl. depths beyond max_depth
+    x[rng.random(x.shape) < 0.3] = 0
+    x[100:140, 300:420] = 0                                               # a 40 x 120 hole: needs the loop
+    got = ctx.complete(x)
+    want, info = O.img_completion(x, return_info=True)
+    assert_bit_equal(got, want, "dense random")
+    assert ctx.last_fill_iters(1)[0][0] == info["fill_iters"]

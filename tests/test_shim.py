@@ -1,0 +1,36 @@
+"""The cv::Mat drop-in (include/img_completion.h): compiles on CPU against the cv::Mat stand-in;
+on the GPU the compiled C++ caller must reproduce the oracle bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bit_equal
+from depth_completion_mt_amd import synth
+
+SH = os.path.join(ROOT, "tests", "mock_opencv", "build_shim_test.sh")
+
+
+def test_shim_compiles_against_the_cv_mat_stand_in():
+    subprocess.run(["bash", SH, "--compile-only"], check=True, capture_output=True)
+
+
+@pytest.mark.gpu
+def test_cpp_caller_matches_oracle(tmp_path):
+    from oracle import oracle as O
+    subprocess.run(["bash", SH], check=True, capture_output=True)
+    rows, cols = 352, 1216
+    x = synth.synth_frame(rows, cols, 4)
+    lab, nl = synth.synth_labels(rows, cols, 1200, 4)
+    x.tofile(tmp_path / "in.f32")
+    lab.tofile(tmp_path / "lab.i32")
+    r = subprocess.run([os.path.join(ROOT, "tests", "mock_opencv", "shim_test"), str(rows), str(cols), str(tmp_path / "in.f32"),
+                        str(tmp_path / "out.f32"), str(tmp_path / "lab.i32"), str(nl), str(tmp_path / "out_lc.f32")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "NUMERO ROWS, COLS: 352 1216" in r.stdout          # the reference prints this (img_completion.cpp:29)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32).reshape(rows, cols)
+    assert_bit_equal(got, O.img_completion(x), "C++ img_completion")
+    got_lc = np.fromfile(tmp_path / "out_lc.f32", dtype=np.float32).reshape(rows, cols)
+    assert_bit_equal(got_lc, O.interpolate_with_superpixels(x, lab, nl), "C++ interpolate_with_superpixels")
