@@ -45,6 +45,7 @@ struct dcmt_ctx {
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
     int fill_cfg = 0;                 // 0: streaming k_fill_s (default); 1: LDS-tile k_fill_t; env DCMT_FILL_CFG
     int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
+    int fuse_fp = 1;                  // H7..H11 in one kernel (k_fp_s); env DCMT_FUSE_FP=0 keeps k_fill_s + k_post_s
 };
 
 namespace {
@@ -173,9 +174,41 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         }
         const int fstrips = (cols + FillS::VW - 1) / FillS::VW;
         const dim3 fgrid(((fstrips + 3) / 4) * nb);
+        if (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->fill_cfg == 0) {
+            // one kernel for H7..H11; frames it leaves with holes are redone by the unfused kernels below
+            const int pstrips = (cols + PostS::VW - 1) / PostS::VW;
+            const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
+            if (bl) hipLaunchKernelGGL((k_fp_s<true>), pg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
+            else    hipLaunchKernelGGL((k_fp_s<false>), pg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
+            DCMT_HIP(ctx, hipGetLastError());
+            ctx->last_has_loop = 1;
+            const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);
+            if (n_redo > 0) {
+                if (sync_loop) {      // host entry points: look before launching anything else
+                    DCMT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(int) * (size_t)batch * kCntStride, hipMemcpyDeviceToHost, st));
+                    DCMT_HIP(ctx, hipStreamSynchronize(st));
+                    bool any = false;
+                    for (int f = 0; f < batch; ++f) any |= ctx->h_counters[(size_t)f * kCntStride + 1] > 0;
+                    if (!any) { if (p->verbose) for (int f = 0; f < batch; ++f) std::printf("0\n"); continue; }
+                }
+                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1);
+                int apps = 0;
+                const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
+                    hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
+                                       fstrips, nb, xm, p->valid_thresh, i, 0);
+                }, &apps);
+                if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
+                if (lrc != DCMT_OK) rc = lrc;
+                apps_all = apps;
+                if (bl) hipLaunchKernelGGL((k_post_s<11, true>), pg, b256, 0, st, pp0, pp1, dst, cnt, apps, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, 1);
+                else    hipLaunchKernelGGL((k_post_s<11, false>), pg, b256, 0, st, pp0, pp1, dst, cnt, apps, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, 1);
+                DCMT_HIP(ctx, hipGetLastError());
+            }
+            continue;
+        }
         if (ctx->fill_cfg == 0) {
             hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
-                               fstrips, nb, xm, p->valid_thresh, 0);
+                               fstrips, nb, xm, p->valid_thresh, 0, 0);
         } else {   // LDS-tile variant (kept for A/B measurements)
             const int tiles = ((cols + FillTile::TW - 1) / FillTile::TW) * ((rows + FillTile::TH - 1) / FillTile::TH);
             hipLaunchKernelGGL((k_fill_t<FillTile>), dim3(tiles * nb), dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0,
@@ -189,7 +222,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
             if (ctx->fill_cfg == 0)
                 hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                                   fstrips, nb, xm, p->valid_thresh, i);
+                                   fstrips, nb, xm, p->valid_thresh, i, 0);
             else
                 hipLaunchKernelGGL((k_fill_loop_t<FillTile>), dim3(nb), dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0,
                                    cnt, rows, cols, p->valid_thresh, i);
@@ -205,7 +238,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const int strips = (cols + PostS::VW - 1) / PostS::VW;
             const dim3 g(((strips + 3) / 4) * nb), b(256);
 #define DCMT_POST(MODE, BLUR) hipLaunchKernelGGL((k_post_s<MODE, BLUR>), g, b, 0, st, pp0, pp1, dst, cnt, apps, rows, cols, strips, \
-                                                 nb, xm, p->max_depth, p->valid_thresh)
+                                                 nb, xm, p->max_depth, p->valid_thresh, 0)
             if (stop == DCMT_STAGE_MEDIAN5) DCMT_POST(9, false);
             else if (stop == DCMT_STAGE_BLUR) { if (bl) DCMT_POST(10, true); else DCMT_POST(10, false); }
             else { if (bl) DCMT_POST(11, true); else DCMT_POST(11, false); }
@@ -410,6 +443,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_XCD_MAP"); if (e) ctx->xcd_map = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FILL_CFG"); if (e) ctx->fill_cfg = std::atoi(e); }
     { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;

@@ -18,6 +18,8 @@
 // Row indices in comments: i = input row of the current step; stage outputs lag behind.
 #pragma once
 
+#include <type_traits>
+
 #include "dcmt_kernels_v1.h"
 #include "median_shared_nets.h"
 
@@ -41,6 +43,16 @@ __device__ __forceinline__ float hmax3(float v) { const float a = fmax2(from_lef
 __device__ __forceinline__ float hmin3(float v) { const float a = fmin2(from_left(v), v); return fmin2(from_right(a), a); }
 __device__ __forceinline__ float hgrow_max(float w) { const float l = from_left(w); return fmax2(from_right(w), l); }
 __device__ __forceinline__ float hgrow_min(float w) { const float l = from_left(w); return fmin2(from_right(w), l); }
+
+// compile-time loop: f(std::integral_constant<int, P>) for P in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 __device__ __forceinline__ int wave_max_i(int v)
 {
@@ -301,128 +313,154 @@ __device__ __forceinline__ float final6(const float (&C)[6], const float (&a)[5]
                  fmin3(fmax2(a[2], C[2]), fmax2(a[3], C[1]), fmax2(a[4], C[0])));
 }
 
+// The streaming post pipeline (H9..H11) of one wave: state + one step.  Shared by k_post_s
+// (input rows from global memory) and k_fp_s (input rows straight from the fill stage).
 // MODE (9/10/11) and BLUR are compile-time: a run-time branch around the ring updates would
-// make every join copy the rings (whole-array phis).
+// make every join copy the rings (whole-array phis).  PP = u & 7 is the static ring phase.
+//
+// Step u takes X7 row clamp(u - 2) (replicate rows), finishes the median of image row u - 4
+// and the output of image row u - 6.
 template <int MODE, bool BLUR>
-__global__ __launch_bounds__(256)
-void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, float* __restrict__ dst,
-              const int* __restrict__ counters, int n_apps_launched, int rows, int cols, int strips,
-              int batch, int xcd_map, float max_depth, float thr)
-{
-    constexpr int mode = MODE;
-    const int lane = threadIdx.x & 63;
-    int f, sg;
-    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
-    const int strip = sg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
-    if (strip >= strips) return;
-    const int a = apps_done(counters + (size_t)f * kCntStride, n_apps_launched);
-    const size_t fo = (size_t)f * rows * cols;
-    const int gx0 = strip * PostS::VW - PostS::H;
-    const int gx = gx0 + lane;
-    const bool outlane = gx >= 0 && gx < cols && lane >= PostS::H && lane < 64 - PostS::H;
-    const int gxc = min(max(gx, 0), cols - 1);                       // BORDER_REPLICATE for the median
-    const float* sp = ((a & 1) ? pp1 : pp0) + fo + gxc;
-    float* op = dst + fo + gxc;
-    // reflect-101 source lane for the Gaussian's out-of-image columns (edge strips only)
-    const int rl = reflect101(gx, cols) - gx0;
-    const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
-    constexpr bool do_blur = BLUR && MODE >= 10;
-
-    // Step t (= u) loads the replicate-clamped input row v = t - 2 and finishes the median of
-    // the window of rows u-4..u, i.e. the median at image row j = t - 4.
+struct PostPipe {
+    static constexpr bool do_blur = BLUR && MODE >= 10;
     float SE[4][5];          // sorted even rows u = 2q, slot q & 3
     float SO[5];             // the latest sorted odd row
     float P[2][10];          // merged pairs (rows 2q-1, 2q), slot q & 1
     float C[6];              // middle order statistics of the current 4-row core
     float G1[8], MR[8];      // horizontal Gaussian / median rows, slot (image row) & 7
-    float PF[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) SE[q][k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) SO[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) { P[0][k] = 0.f; P[1][k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) C[k] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { G1[q] = 0.f; MR[q] = 0.f; PF[q] = 0.f; }
+    // per-lane constants
+    float* op;               // output column of this lane
+    int rows, cols, gx, rl;
+    bool outlane, edge_strip;
+    float max_depth, thr;
 
+    __device__ __forceinline__ void init(float* out_col, int rows_, int cols_, int gx0, int lane, float max_depth_, float thr_)
+    {
+        op = out_col; rows = rows_; cols = cols_; max_depth = max_depth_; thr = thr_;
+        gx = gx0 + lane;
+        outlane = gx >= 0 && gx < cols && lane >= PostS::H && lane < 64 - PostS::H;
+        rl = reflect101(gx, cols) - gx0;      // reflect-101 source lane for the Gaussian's out-of-image columns
+        edge_strip = gx0 < 0 || gx0 + 63 >= cols;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SE[q][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) SO[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { P[0][k] = 0.f; P[1][k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { G1[q] = 0.f; MR[q] = 0.f; }
+    }
+
+    template <int PP>
+    __device__ __forceinline__ void step(float x, int u)
+    {
+        // ---- H9 (LO :170)
+        float s[5];
+        {
+            const float l1 = from_left(x), r1 = from_right(x);
+            s[0] = from_left(l1); s[1] = l1; s[2] = x; s[3] = r1; s[4] = from_right(r1);
+        }
+        sort5(s);
+        float m;
+        if constexpr ((PP & 1) == 0) {                                // u = 2q
+            constexpr int qs = (PP >> 1) & 3;
+            merge55(SO, s, P[(PP >> 1) & 1]);                         // rows u-1, u
+            mid20(P[((PP >> 1) + 1) & 1], P[(PP >> 1) & 1], C);       // core rows u-3 .. u
+            m = final6(C, SE[(qs + 2) & 3]);                          // + row u-4
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SE[qs][k] = s[k];
+        } else {                                                      // u = 2q + 1
+            m = final6(C, s);                                         // core rows u-4 .. u-1, + row u
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SO[k] = s[k];
+        }
+        const int j = u - 4;                                           // image row of this median
+        if constexpr (MODE == 9) {
+            if ((unsigned)j < (unsigned)rows && outlane) op[(size_t)j * cols] = m;
+            return;
+        }
+        MR[(PP + 4) & 7] = m;
+        // ---- H10 (LO :179): horizontal [1 4 6 4 1]/16 with reflect-101 columns
+        if constexpr (do_blur) {
+            float mf = m;
+            if (edge_strip) { const float mr = __shfl(m, rl, 64); mf = (gx < 0 || gx >= cols) ? mr : m; }
+            const float ml1 = from_left(mf), mr1 = from_right(mf);
+            const float ml2 = from_left(ml1), mr2 = from_right(mr1);
+            float acc = __fmul_rn(mf, 0.375f);
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml1, mr1), 0.25f));
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml2, mr2), 0.0625f));
+            G1[(PP + 4) & 7] = acc;
+        }
+        // ---- vertical pass + select + invert for output row o = j - 2 = u - 6
+        const int o = u - 6;
+        if ((unsigned)o < (unsigned)rows) {
+            // slots: row o -> (PP+2)&7, o+1 -> PP+3, o+2 -> PP+4, o-1 -> PP+1, o-2 -> PP
+            const float mo = MR[(PP + 2) & 7];
+            float val = mo;
+            if constexpr (do_blur) {
+                const float g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7];
+                const float g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];
+                float u1 = g_m1, u2 = g_m2, d1 = g_p1, d2 = g_p2;
+                if (o < 2 || o + 2 >= rows) {                            // reflect-101 rows (rows >= 8 guaranteed)
+                    u1 = o >= 1 ? g_m1 : g_p1;
+                    u2 = o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2);
+                    d1 = o + 1 < rows ? g_p1 : g_m1;
+                    d2 = o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2);
+                }
+                float acc = __fmul_rn(g_0, 0.375f);
+                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
+                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
+                if (mo >= thr) val = acc;                               // LO :184
+            }
+            if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
+            if (outlane) op[(size_t)o * cols] = val;
+        }
+    }
+};
+
+// only_if_holes: recompute pass behind k_fp_s -- frames that needed no loop application are
+// already final and are skipped.
+template <int MODE, bool BLUR>
+__global__ __launch_bounds__(256)
+void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, float* __restrict__ dst,
+              const int* __restrict__ counters, int n_apps_launched, int rows, int cols, int strips,
+              int batch, int xcd_map, float max_depth, float thr, int only_if_holes)
+{
+    const int lane = threadIdx.x & 63;
+    int f, sg;
+    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
+    const int strip = sg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
+    if (strip >= strips) return;
+    const int* cnt = counters + (size_t)f * kCntStride;
+    if (only_if_holes && cnt[1] == 0) return;
+    const int a = apps_done(cnt, n_apps_launched);
+    const size_t fo = (size_t)f * rows * cols;
+    const int gx0 = strip * PostS::VW - PostS::H;
+    const int gxc = min(max(gx0 + lane, 0), cols - 1);               // BORDER_REPLICATE for the median
+    const float* sp = ((a & 1) ? pp1 : pp0) + fo + gxc;
+    PostPipe<MODE, BLUR> pipe;
+    pipe.init(dst + fo + gxc, rows, cols, gx0, lane, max_depth, thr);
+
+    float PF[8];
     constexpr int PFD = 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) PF[q] = 0.f;
 #pragma unroll
     for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - 2, 0), rows - 1) * cols];
 
     const int nsteps = rows + 6;                 // the last output row o = t - 6 = rows - 1
     for (int t0 = 0; t0 < nsteps; t0 += 8) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        static_for<0, 8>([&](auto P_) {
+            constexpr int p = decltype(P_)::value;
             const int t = t0 + p;
             const float x = PF[p];
             PF[(p + PFD) & 7] = sp[(size_t)min(max(t + PFD - 2, 0), rows - 1) * cols];
-            // ---- H9 (LO :170)
-            float s[5];
-            {
-                const float l1 = from_left(x), r1 = from_right(x);
-                s[0] = from_left(l1); s[1] = l1; s[2] = x; s[3] = r1; s[4] = from_right(r1);
-            }
-            sort5(s);
-            float m;
-            if ((p & 1) == 0) {                                       // u = 2q
-                constexpr int dummy = 0; (void)dummy;
-                const int qs = (p >> 1) & 3;
-                merge55(SO, s, P[(p >> 1) & 1]);                      // rows u-1, u
-                mid20(P[((p >> 1) + 1) & 1], P[(p >> 1) & 1], C);     // core rows u-3 .. u
-                m = final6(C, SE[(qs + 2) & 3]);                      // + row u-4
-#pragma unroll
-                for (int k = 0; k < 5; ++k) SE[qs][k] = s[k];
-            } else {                                                  // u = 2q + 1
-                m = final6(C, s);                                     // core rows u-4 .. u-1, + row u
-#pragma unroll
-                for (int k = 0; k < 5; ++k) SO[k] = s[k];
-            }
-            const int j = t - 4;                                       // image row of this median
-            if constexpr (mode == 9) {
-                if ((unsigned)j < (unsigned)rows && outlane) op[(size_t)j * cols] = m;
-                continue;
-            }
-            MR[(p + 4) & 7] = m;
-            // ---- H10 (LO :179): horizontal [1 4 6 4 1]/16 with reflect-101 columns
-            if constexpr (do_blur) {
-                float mf = m;
-                if (edge_strip) { const float mr = __shfl(m, rl, 64); mf = (gx < 0 || gx >= cols) ? mr : m; }
-                const float ml1 = from_left(mf), mr1 = from_right(mf);
-                const float ml2 = from_left(ml1), mr2 = from_right(mr1);
-                float acc = __fmul_rn(mf, 0.375f);
-                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml1, mr1), 0.25f));
-                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml2, mr2), 0.0625f));
-                G1[(p + 4) & 7] = acc;
-            }
-            // ---- vertical pass + select + invert for output row o = j - 2 = t - 6
-            const int o = t - 6;
-            if ((unsigned)o < (unsigned)rows) {
-                // slots: row o -> (p+2)&7, o+1 -> p+3, o+2 -> p+4, o-1 -> p+1, o-2 -> p
-                const float mo = MR[(p + 2) & 7];
-                float val = mo;
-                if constexpr (do_blur) {
-                    const float g_p2 = G1[(p + 4) & 7], g_p1 = G1[(p + 3) & 7], g_0 = G1[(p + 2) & 7];
-                    const float g_m1 = G1[(p + 1) & 7], g_m2 = G1[p];
-                    float u1 = g_m1, u2 = g_m2, d1 = g_p1, d2 = g_p2;
-                    if (o < 2 || o + 2 >= rows) {                        // reflect-101 rows (rows >= 8 guaranteed)
-                        u1 = o >= 1 ? g_m1 : g_p1;
-                        u2 = o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2);
-                        d1 = o + 1 < rows ? g_p1 : g_m1;
-                        d2 = o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2);
-                    }
-                    float acc = __fmul_rn(g_0, 0.375f);
-                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
-                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
-                    if (mo >= thr) val = acc;                           // LO :184
-                }
-                if constexpr (mode >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
-                if (outlane) op[(size_t)o * cols] = val;
-            }
-        }
+            pipe.template step<p>(x, t);
+        });
     }
 }
 
@@ -442,6 +480,7 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
 // the -FLT_MAX constant border, so all loads are simply clamped into the image: no masks.
 // app == 0: H7, counts the holes it sees (cnt[0]) and leaves (cnt[1]).
 // app >= 1: loop iteration; frames whose previous application left no holes return at once.
+// redo:     application 0 again, without counting, for the frames k_fp_s could not finish.
 // ---------------------------------------------------------------------------------
 struct FillS {
     static constexpr int R = 15;
@@ -465,7 +504,7 @@ __device__ __forceinline__ float row_suffix_max(float x) { max_shl1(x); max_shl2
 
 __global__ __launch_bounds__(256)
 void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app)
+              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo)
 {
     const int lane = threadIdx.x & 63;
     int f, sg;
@@ -474,6 +513,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     if (strip >= strips) return;
     int* cnt = frame_counters(counters, f);
     if (app >= 1 && cnt[app] == 0) return;       // holes left by application app-1: none
+    if (redo && cnt[1] == 0) return;             // redo of application 0 behind k_fp_s: only frames that need the loop
     const int gx = strip * FillS::VW - FillS::R + lane;
     const bool outlane = gx >= 0 && gx < cols && lane >= FillS::R && lane < 64 - FillS::R;
     const size_t fo = (size_t)f * rows * cols;
@@ -533,9 +573,167 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     // hole counts of this strip
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) { before += __shfl_xor(before, sh, 64); after += __shfl_xor(after, sh, 64); }
-    if (lane == 0) {
+    if (lane == 0 && !redo) {                     // a redo recomputes what k_fp_s already counted
         if (app == 0 && before) atomicAdd(&cnt[0], before);
         if (after) atomicAdd(&cnt[1 + app], after);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_fp_s : k_fill_s (application 0) and k_post_s in ONE streaming kernel -- X7 never goes to
+// memory.  One wave64 owns the 64 columns of a post strip (56 of them produce output).
+//
+// The 31-wide horizontal maximum needs 15 more columns on each side.  They ride in a second
+// register per lane ("B"): lanes 0..14 hold the 15 columns right of the strip, lanes 49..63
+// the 15 columns left of it, so that both are whole 16-lane DPP rows and the same
+// prefix / suffix row scans apply.  With M = max(P, S) of the lane's own 16-block:
+//     out(c) = max( S'((c - 15) mod 64), M(c), P'((c + 15) mod 64) ),
+//     S' = lane >= 49 ? S_B : S_A,   P' = lane <= 14 ? P_B : P_A
+// -- the wrap-around of the two ds_bpermutes lands exactly on the B lanes.  Every one of the 64
+// lanes therefore gets its exact X7 value, and the post pipeline (PostPipe) runs on it in the
+// same step, 32 steps later than the fill front end (30 rows of fill latency + its own 2 rows
+// of replicate padding): step t feeds X7 row clamp(t - 34) to post step u = t - 32.
+//
+// The vertical 31-max of both registers is the doubling of k_fill_s; the two 15-step delays that
+// are only read once (the centre values and the B register's 16-row maxima) live in a
+// wave-private LDS delay line instead of 32 VGPRs.
+//
+// Correct only for frames that need no hole-closure loop application (the common case: every
+// hole is filled by H7).  The kernel counts the holes it leaves per frame (cnt[1]); frames with
+// cnt[1] > 0 are recomputed afterwards by k_fill_s / k_post_s (their only_if_holes modes).
+// ---------------------------------------------------------------------------------
+struct FpS {
+    static constexpr int LAG = 32;               // post step u = t - LAG
+};
+
+template <bool BLUR>
+__global__ __launch_bounds__(256)
+void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
+            int rows, int cols, int strips, int batch, int xcd_map, float max_depth, float thr)
+{
+    // per wave, three 15-step delay lines: centre values, A's 16-row maxima (64 lanes each), B's 16-row
+    // maxima (only its 30 halo lanes: packed to 32) -- 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
+    __shared__ float s_delay[4][16 * (64 + 64 + 32)];
+    const int lane = threadIdx.x & 63;
+    int f, sg;
+    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = sg * 4 + wave;
+    if (strip >= strips) return;
+    int* cnt = frame_counters(counters, f);
+    const size_t fo = (size_t)f * rows * cols;
+    const int gx0 = strip * PostS::VW - PostS::H;
+    const int gxa = gx0 + lane;
+    const int gxb = lane <= 14 ? gx0 + 64 + lane : (lane >= 49 ? gx0 - 64 + lane : gxa);
+    const float* spa = x6 + fo + min(max(gxa, 0), cols - 1);       // clamped: replicate == constant border for a max filter
+    const float* spb = x6 + fo + min(max(gxb, 0), cols - 1);
+    const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
+    const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
+    const int src_lane = min(max(gxa, 0), cols - 1) - gx0;          // BORDER_REPLICATE columns for the median
+    const int a_lo = ((lane - 15) & 63) * 4, a_hi = ((lane + 15) & 63) * 4;
+    float (*dl_c)[64] = reinterpret_cast<float (*)[64]>(s_delay[wave]);
+    float (*dl_a)[64] = reinterpret_cast<float (*)[64]>(s_delay[wave] + 16 * 64);
+    float (*dl_b)[32] = reinterpret_cast<float (*)[32]>(s_delay[wave] + 16 * 128);
+    const int lb = lane <= 14 ? lane : (lane >= 49 ? lane - 32 : 15 + (lane & 1));   // B's live lanes 0..14, 49..63 -> 0..14, 17..31; the rest share two junk words
+
+    PostPipe<11, BLUR> pipe;
+    pipe.init(dst + fo + min(max(gxa, 0), cols - 1), rows, cols, gx0, lane, max_depth, thr);
+
+    constexpr float NEG = -FLT_MAX;
+    float PFA[16], PFB[16], W2A[16], W4A[16], W8A[16], W2B[16], W4B[16], W8B[16], DL[8];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { PFA[q] = PFB[q] = 0.f; W2A[q] = W4A[q] = W8A[q] = W2B[q] = W4B[q] = W8B[q] = NEG; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) DL[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { dl_c[q][lane] = NEG; dl_a[q][lane] = NEG; dl_b[q][lb] = NEG; }
+    constexpr int PFD = 4;
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) {
+        const size_t ro = (size_t)min(max(q - 15, 0), rows - 1) * cols;
+        PFA[q] = spa[ro]; PFB[q] = spb[ro];
+    }
+    float vpa = NEG, vpb = NEG, x7_first = 0.f, x7_last = 0.f;
+    int before = 0, after = 0;
+    // Software skew: the two ds_bpermutes and the two delay-line reads issued in step t are consumed
+    // in step t + 1, so their LDS round trips overlap the next step's arithmetic instead of
+    // stalling the wave (s_waitcnt) three times per step.
+    float pend_m = NEG, pend_v = NEG, pend_slo = NEG, pend_phi = NEG;   // of stream row t - 1
+    float nxt_c = NEG, nxt_a = NEG, nxt_b = NEG;                         // delay-line values for the next step
+
+    // the fill front end of step t: returns X7 of image row t - 31 for every lane
+    auto fill_step = [&](auto P_, int t) -> float {
+        constexpr int p = decltype(P_)::value;
+        const float xa = PFA[p], xb = PFB[p];
+        {
+            const size_t ro = (size_t)min(max(t + PFD - 15, 0), rows - 1) * cols;
+            PFA[(p + PFD) & 15] = spa[ro]; PFB[(p + PFD) & 15] = spb[ro];
+        }
+        // finish row t - 1 - 30 from what step t - 1 left pending
+        const float d = fmax3(pend_m, pend_slo, pend_phi);
+        const bool hole = pend_v < thr;                             // LO :140
+        float x7 = hole ? d : pend_v;
+        const int o = t - 31;
+        if ((unsigned)o < (unsigned)rows && own) { before += hole; after += x7 < thr; }
+        if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
+        if (o == 0) x7_first = x7;
+        if (o == rows - 1) x7_last = x7;
+        // vertical 31-max, both registers (see k_fill_s)
+        const float w2a = fmax2(xa, vpa), w2b = fmax2(xb, vpb);
+        vpa = xa; vpb = xb;
+        W2A[p] = w2a; W2B[p] = w2b;
+        const float w4a = fmax2(w2a, W2A[(p + 14) & 15]), w4b = fmax2(w2b, W2B[(p + 14) & 15]);
+        W4A[p] = w4a; W4B[p] = w4b;
+        const float w8a = fmax2(w4a, W4A[(p + 12) & 15]), w8b = fmax2(w4b, W4B[(p + 12) & 15]);
+        W8A[p] = w8a; W8B[p] = w8b;
+        const float w16a = fmax2(w8a, W8A[(p + 8) & 15]), w16b = fmax2(w8b, W8B[(p + 8) & 15]);
+        // LDS delay lines: slot (t & 15) is written now; slot ((t + 1) & 15), written 15 steps ago, was
+        // fetched during the previous step, and slot ((t + 2) & 15) is fetched now for the next one
+        const float v = nxt_c, w16a_old = nxt_a, w16b_old = nxt_b;  // stream row t - 15
+        nxt_c = dl_c[(p + 2) & 15][lane];
+        nxt_a = dl_a[(p + 2) & 15][lane];
+        nxt_b = dl_b[(p + 2) & 15][lb];
+        dl_c[p][lane] = xa;
+        dl_a[p][lane] = w16a;
+        dl_b[p][lb] = w16b;
+        const float w31a = fmax2(w16a, w16a_old), w31b = fmax2(w16b, w16b_old);
+        // horizontal 31-max: scans now, the cross-row fetches land during the next step
+        const float PA = row_prefix_max(w31a), SA = row_suffix_max(w31a);
+        const float PB = row_prefix_max(w31b), SB = row_suffix_max(w31b);
+        const float Sm = lane >= 49 ? SB : SA, Pm = lane <= 14 ? PB : PA;
+        pend_slo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_lo, __builtin_bit_cast(int, Sm)));
+        pend_phi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_hi, __builtin_bit_cast(int, Pm)));
+        pend_m = fmax2(PA, SA);
+        pend_v = v;
+        return x7;
+    };
+
+    // steps 0..31: fill only (X7 row 0 appears at t = 31)
+    for (int t0 = 0; t0 < FpS::LAG; t0 += 16) {
+        static_for<0, 16>([&](auto P_) {
+            constexpr int p = decltype(P_)::value;
+            DL[p & 7] = fill_step(P_, t0 + p);
+        });
+    }
+    // steps 32..rows+37: fill + post; post step u = t - 32 takes X7 row clamp(u - 2) = clamp(t - 34),
+    // which the fill front end produced 3 steps ago
+    const int nsteps = rows + 38;
+    for (int t0 = FpS::LAG; t0 < nsteps; t0 += 16) {
+        static_for<0, 16>([&](auto P_) {
+            constexpr int p = decltype(P_)::value;
+            const int t = t0 + p, u = t - FpS::LAG;
+            DL[p & 7] = fill_step(P_, t);
+            float xin = DL[(p + 5) & 7];
+            if (u < 2) xin = x7_first;
+            if (u - 2 >= rows) xin = x7_last;
+            pipe.template step<(p & 7)>(xin, u);
+        });
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) { before += __shfl_xor(before, sh, 64); after += __shfl_xor(after, sh, 64); }
+    if (lane == 0) {
+        if (before) atomicAdd(&cnt[0], before);
+        if (after) atomicAdd(&cnt[1], after);
     }
 }
 
