@@ -43,9 +43,9 @@ struct dcmt_ctx {
     int poison = 0;                   // env DCMT_POISON=1: fill the staging output with NaN before every host call
     int chunk = 0;                    // frames per chunk of the fused path (0 = whole batch); env DCMT_CHUNK
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
-    int fill_cfg = 0;                 // 0: streaming k_fill_s (default); 1: LDS-tile k_fill_t; env DCMT_FILL_CFG
     int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
     int fuse_fp = 1;                  // H7..H11 in one kernel (k_fp_s); env DCMT_FUSE_FP=0 keeps k_fill_s + k_post_s
+    int min_fused_batch = 4;          // smaller batches use the staged kernels; env DCMT_MIN_FUSED_BATCH
 };
 
 namespace {
@@ -84,7 +84,6 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
 
 dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
 
-using FillTile = FillT<30, 94>;     // LDS-tile variant of the 31x31 fill (env DCMT_FILL_CFG=1); the default is k_fill_s
 
 int k0_preset(uint32_t kb)
 {
@@ -174,7 +173,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         }
         const int fstrips = (cols + FillS::VW - 1) / FillS::VW;
         const dim3 fgrid(((fstrips + 3) / 4) * nb);
-        if (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->fill_cfg == 0) {
+        if (stop == DCMT_STAGE_FINAL && ctx->fuse_fp) {
             // one kernel for H7..H11; frames it leaves with holes are redone by the unfused kernels below
             const int pstrips = (cols + PostS::VW - 1) / PostS::VW;
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
@@ -206,26 +205,16 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             }
             continue;
         }
-        if (ctx->fill_cfg == 0) {
-            hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
-                               fstrips, nb, xm, p->valid_thresh, 0, 0);
-        } else {   // LDS-tile variant (kept for A/B measurements)
-            const int tiles = ((cols + FillTile::TW - 1) / FillTile::TW) * ((rows + FillTile::TH - 1) / FillTile::TH);
-            hipLaunchKernelGGL((k_fill_t<FillTile>), dim3(tiles * nb), dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0,
-                               cnt, rows, cols, nb, xm, p->valid_thresh);
-        }
+        hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
+                           fstrips, nb, xm, p->valid_thresh, 0, 0);
         DCMT_HIP(ctx, hipGetLastError());
         if (stop == DCMT_STAGE_FILL31) continue;
 
         ctx->last_has_loop = 1;
         int apps = 0;
         const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
-            if (ctx->fill_cfg == 0)
-                hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                                   fstrips, nb, xm, p->valid_thresh, i, 0);
-            else
-                hipLaunchKernelGGL((k_fill_loop_t<FillTile>), dim3(nb), dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0,
-                                   cnt, rows, cols, p->valid_thresh, i);
+            hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
+                               fstrips, nb, xm, p->valid_thresh, i, 0);
         }, &apps);
         if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
         if (lrc != DCMT_OK) rc = lrc;
@@ -264,7 +253,10 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     {
         const int kind = k0_preset(kb);
         const bool labeled = d_labels && use_superpixel;
-        if (!(p->flags & DCMT_FLAG_FORCE_STAGED) && !labeled && kind >= 0 && rows >= 8 && cols >= 8 &&
+        // the streaming kernels give one wave a whole column strip: a handful of frames cannot fill the
+        // GPU with them, there the staged tile kernels (hundreds of small workgroups per frame) win
+        const bool big_enough = batch >= ctx->min_fused_batch || (p->flags & DCMT_FLAG_FORCE_FUSED);
+        if (!(p->flags & DCMT_FLAG_FORCE_STAGED) && big_enough && !labeled && kind >= 0 && rows >= 8 && cols >= 8 &&
             stop >= DCMT_STAGE_EXTEND) {
             dcmt_params q = *p;
             q.blur = blur;
@@ -441,9 +433,9 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_POISON"); ctx->poison = e && e[0] == '1'; }
     { const char* e = std::getenv("DCMT_CHUNK"); if (e) ctx->chunk = std::atoi(e); }
     { const char* e = std::getenv("DCMT_XCD_MAP"); if (e) ctx->xcd_map = std::atoi(e); }
-    { const char* e = std::getenv("DCMT_FILL_CFG"); if (e) ctx->fill_cfg = std::atoi(e); }
     { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;

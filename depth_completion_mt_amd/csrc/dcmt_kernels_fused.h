@@ -1,6 +1,6 @@
 // dcmt_kernels_fused.h -- the fast path for the default configuration (a preset first
-// element, the whole chain, images of at least 8x8): three launches per batch, the hot
-// stencils held entirely in registers.
+// element, images of at least 8x8): two launches per batch (k_pre_s, k_fp_s), the hot
+// stencils held entirely in registers, no barriers, LDS only as wave-private delay lines.
 //
 //   k_pre_s   H2..H6   one wave64 owns a strip of columns over the FULL image height and
 //                      streams down the rows: lane = column, vertical windows live in
@@ -9,11 +9,12 @@
 //                      Because the wave sees whole columns, the column extension (H6) needs
 //                      no second kernel and no atomics: first/last valid row are tracked in
 //                      registers and the extension zones are written in the epilogue.
-//   k_fill_t   H7 (+H8) 31x31 dilate-fill on an LDS tile: the horizontal 31-max runs with
-//                      lane = row (a transposed walk over the odd-pitch tile), the vertical
-//                      one with lane = column; both are sliding maxima in registers.
-//   k_post_s  H9..H11  streaming like k_pre_s: 5x5 median from DPP-gathered neighbours,
-//                      separable Gaussian, masked select, final invert.
+//   k_fp_s    H7..H11  the same streaming layout: 31x31 dilate-fill (vertical doubling in
+//                      registers, horizontal 16-lane DPP prefix/suffix scans + two ds_bpermutes),
+//                      feeding the 5x5 median (time-shared sorting networks), the separable
+//                      Gaussian, the masked select and the final invert in the same step.
+//   k_fill_s / k_post_s  the two halves of k_fp_s as separate kernels: the hole-closure loop
+//                      (H8) for the rare frames that need it, and the stop_after probes.
 //
 // Row indices in comments: i = input row of the current step; stage outputs lag behind.
 #pragma once
@@ -735,174 +736,6 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         if (before) atomicAdd(&cnt[0], before);
         if (after) atomicAdd(&cnt[1], after);
     }
-}
-
-// ---------------------------------------------------------------------------------
-// k_fill_t : x = x < 0.1 ? dilate31(x) : x on an LDS tile (LO :131-144 and one iteration of
-// :146-166).  The 31-wide maxima are sliding maxima in registers over a fully unrolled
-// stream: w3 -> w9 -> w27 -> w31 (three v_max3 and one v_max per element).
-//   pass V (lane = column): streams DOWN the rows straight from global memory (coalesced
-//           rows), vertical 31-max -> LDS plane V [TH][RW]
-//   pass H (lane = row):    streams ALONG the columns of V (odd pitch: conflict-free),
-//           horizontal 31-max -> LDS plane D [TH][TW]
-//   select (lane = column): out = x < thr ? D : x, coalesced store, hole counts
-// ---------------------------------------------------------------------------------
-template <int TH_, int TW_, int RP_ = 2, int SG_ = 4>
-struct FillT {
-    static constexpr int TH = TH_, TW = TW_, R = 15;
-    static constexpr int RW = TW + 2 * R;          // input columns a tile needs
-    static constexpr int PV = RW | 1, PD = TW | 1; // odd pitches
-    static constexpr int LG = (RW + 63) / 64;      // lane groups of pass V
-    static constexpr int RP = RP_;                 // row parts of pass V
-    static constexpr int NSV = (TH + RP - 1) / RP + 2 * R;   // steps of one pass-V task
-    static constexpr int RG = (TH + 63) / 64;      // row groups of pass H
-    static constexpr int SG = SG_;                 // column segments of pass H
-    static constexpr int NSH = (TW + SG - 1) / SG + 2 * R;   // steps of one pass-H task
-    static constexpr int LDS_FLOATS = TH * PV + TH * PD;
-};
-
-// one sliding 31-max stream of N steps; get(s) supplies element s, put(s - 30, w) receives the
-// maximum of elements s-30..s for every s >= 30
-template <int N, typename Get, typename Put>
-__device__ __forceinline__ void sliding_max31(Get get, Put put)
-{
-    constexpr float NEG = -FLT_MAX;
-    float v[N], w3[N], w9[N], w27[N];
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-        v[s] = get(s);
-        w3[s] = fmax3(v[s], s >= 1 ? v[s - 1] : NEG, s >= 2 ? v[s - 2] : NEG);
-        w9[s] = fmax3(w3[s], s >= 3 ? w3[s - 3] : NEG, s >= 6 ? w3[s - 6] : NEG);
-        w27[s] = fmax3(w9[s], s >= 9 ? w9[s - 9] : NEG, s >= 18 ? w9[s - 18] : NEG);
-        if (s >= 30) put(s - 30, fmax2(w27[s], w27[s - 4]));
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void fill_tile(const float* __restrict__ xin, float* __restrict__ xout, float* lds,
-                                          int rows, int cols, int ty, int tx, float thr, int& before, int& after)
-{
-    float* Vp = lds;
-    float* Dp = lds + T::TH * T::PV;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave id: scalar
-    const int gy0 = ty * T::TH, gx0 = tx * T::TW;       // image coordinates of the tile origin
-
-    // pass V
-    for (int task = wave; task < T::LG * T::RP; task += 4) {
-        const int lg = task % T::LG, rp = task / T::LG;
-        const int x = lg * 64 + lane;                   // region column
-        const int gx = gx0 - T::R + x;
-        const bool act = x < T::RW;
-        const int o0 = rp * T::TH / T::RP, o1 = (rp + 1) * T::TH / T::RP;   // output rows of this part
-        // Loads are unconditional, from addresses clamped into the image: a max filter whose
-        // centre is inside the image gives the same result with a replicated border as with the
-        // -FLT_MAX constant border (the border row/column is itself in the window), so neither
-        // rows nor columns need a sentinel select -- and a predicated load would make hipcc branch
-        // around every load and wait for each one in turn.
-        const float* colp = xin + min(max(gx, 0), cols - 1);
-        sliding_max31<T::NSV>(
-            [&](int s) { return colp[(size_t)min(max(gy0 - T::R + o0 + s, 0), rows - 1) * cols]; },
-            [&](int so, float w) {
-                if (act && o0 + so < o1) Vp[(o0 + so) * T::PV + x] = w;
-            });
-    }
-    __syncthreads();
-    // pass H
-    for (int task = wave; task < T::RG * T::SG; task += 4) {
-        const int rg = task % T::RG, sg = task / T::RG;
-        const int y = rg * 64 + lane;
-        const bool act = y < T::TH;
-        const int xo0 = sg * T::TW / T::SG, xo1 = (sg + 1) * T::TW / T::SG;
-        const float* rowp = Vp + (act ? y : 0) * T::PV;
-        sliding_max31<T::NSH>(
-            [&](int s) { return rowp[min(xo0 + s, T::RW - 1)]; },
-            [&](int so, float w) {
-                if (act && xo0 + so < xo1) Dp[y * T::PD + xo0 + so] = w;
-            });
-    }
-    __syncthreads();
-    // select + store + hole counts
-    {
-        constexpr int NPX = T::TH * T::TW, NIT = (NPX + kThreads - 1) / kThreads;
-        float vin[NIT], vd[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {                  // all loads first, from clamped addresses
-            const int i = min((int)threadIdx.x + k * kThreads, NPX - 1);
-            const int y = i / T::TW, x = i - y * T::TW;
-            vin[k] = xin[(size_t)min(gy0 + y, rows - 1) * cols + min(gx0 + x, cols - 1)];
-            vd[k] = Dp[y * T::PD + x];
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = threadIdx.x + k * kThreads;
-            const int y = i / T::TW, x = i - y * T::TW;
-            const int gy = gy0 + y, gx = gx0 + x;
-            if (i < NPX && gy < rows && gx < cols) {
-                const float v = vin[k];
-                const bool hole = v < thr;               // LO :140 / :154
-                const float o = hole ? vd[k] : v;
-                xout[(size_t)gy * cols + gx] = o;
-                before += hole;
-                after += o < thr;
-            }
-        }
-    }
-    __syncthreads();                                     // the planes are reused by the next tile (loop kernel)
-}
-
-__device__ __forceinline__ int block_sum(int v, int* s_tmp)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const int r = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
-    __syncthreads();
-    return r;
-}
-
-// application 0 (H7) over the whole batch: 1-D grid of batch * tiles workgroups (frame_unit mapping)
-template <typename T>
-__global__ __launch_bounds__(256)
-void k_fill_t(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, int batch, int xcd_map, float thr)
-{
-    __shared__ float lds[T::LDS_FLOATS];
-    __shared__ int s_tmp[4];
-    const int txn = (cols + T::TW - 1) / T::TW, tyn = (rows + T::TH - 1) / T::TH;
-    int f, u;
-    frame_unit(blockIdx.x, txn * tyn, batch, xcd_map, f, u);
-    const size_t fo = (size_t)f * rows * cols;
-    int before = 0, after = 0;
-    fill_tile<T>(in + fo, out + fo, lds, rows, cols, u / txn, u % txn, thr, before, after);
-    const int b = block_sum(before, s_tmp), a = block_sum(after, s_tmp);
-    if (threadIdx.x == 0) {
-        int* cnt = frame_counters(counters, f);
-        if (b) atomicAdd(&cnt[0], b);
-        if (a) atomicAdd(&cnt[1], a);
-    }
-}
-
-// application app >= 1 (one iteration of the H8 loop): one workgroup per frame; frames whose
-// previous application left no holes return at once (the common case), the others walk their
-// tiles.  An application without holes changes nothing, so skipping it is exact.
-template <typename T>
-__global__ __launch_bounds__(256)
-void k_fill_loop_t(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-                   int rows, int cols, float thr, int app)
-{
-    __shared__ float lds[T::LDS_FLOATS];
-    __shared__ int s_tmp[4];
-    const int f = blockIdx.x;
-    int* cnt = frame_counters(counters, f);
-    if (cnt[app] == 0) return;                           // holes left by application app-1
-    const size_t fo = (size_t)f * rows * cols;
-    const int tyn = (rows + T::TH - 1) / T::TH, txn = (cols + T::TW - 1) / T::TW;
-    int before = 0, after = 0;
-    for (int t = 0; t < tyn * txn; ++t)
-        fill_tile<T>(in + fo, out + fo, lds, rows, cols, t / txn, t % txn, thr, before, after);
-    const int a = block_sum(after, s_tmp);
-    if (threadIdx.x == 0) cnt[1 + app] = a;
 }
 
 }  // namespace dcmt

@@ -85,6 +85,10 @@ typedef struct {
 /* Use the general staged kernels even where the fused fast path applies (A/B tests, debugging).
  * Both paths produce identical bits. */
 #define DCMT_FLAG_FORCE_STAGED 1
+/* Use the fused streaming kernels even for a batch too small to fill the GPU with them (by default
+ * batches of fewer than 4 frames take the staged tile kernels, whose many small workgroups have the
+ * lower latency for a single frame).  Both paths produce identical bits. */
+#define DCMT_FLAG_FORCE_FUSED 2
 
 /* ---- lifetime --------------------------------------------------------------------- */
 

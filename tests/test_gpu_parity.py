@@ -45,6 +45,9 @@ def test_per_stage_goldens(ctx, golden):
     for st in range(2, 12):
         got = ctx.complete(x, api.make_params(stop_after=st))
         assert_bit_equal(got, golden[f"crop48x64_stage{st}"], f"HIP stage {st}")
+        if st >= 6:      # the fused streaming kernels on the same single frame
+            got = ctx.complete(x, api.make_params(stop_after=st, force_fused=True))
+            assert_bit_equal(got, golden[f"crop48x64_stage{st}"], f"HIP fused stage {st}")
     assert_bit_equal(ctx.complete(x, api.make_params(k0="diamond")), golden["crop48x64_diamond"], "diamond")
     assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none")), golden["crop48x64_noblur"], "no blur")
     assert_bit_equal(ctx.complete(golden["odd33x70_in"]), golden["odd33x70_out"], "33x70")
@@ -54,19 +57,21 @@ def test_per_stage_goldens(ctx, golden):
 def test_adversarial_goldens(ctx, golden, golden_meta):
     for name, info in golden_meta["adversarial"].items():
         x = golden[f"adv_{name}_in"]
-        got = ctx.complete(x, api.make_params(max_fill_iters=8), allow_not_converged=True)
-        assert_bit_equal(got, golden[f"adv_{name}_out"], f"adversarial {name}")
-        iters, st = ctx.last_fill_iters(1)
-        assert st == L.OK and iters[0] == info["fill_iters"], (name, iters, info)
-        assert ctx.last_holes_after_extend(1)[0] == info["holes_after_extend"], name
+        for fused in (False, True):
+            got = ctx.complete(x, api.make_params(max_fill_iters=8, force_fused=fused), allow_not_converged=True)
+            assert_bit_equal(got, golden[f"adv_{name}_out"], f"adversarial {name} fused={fused}")
+            iters, st = ctx.last_fill_iters(1)
+            assert st == L.OK and iters[0] == info["fill_iters"], (name, iters, info)
+            assert ctx.last_holes_after_extend(1)[0] == info["holes_after_extend"], name
 
 
 def test_fill_loop_cap(ctx, golden, O):
     x = golden["adv_tall_gap_in"]
-    got = ctx.complete(x, api.make_params(max_fill_iters=2), allow_not_converged=True)
-    assert ctx.last_status == L.E_NOT_CONVERGED
     want = O.img_completion(x, O.default_params(max_fill_iters=2))
-    assert_bit_equal(got, want, "capped loop")
+    for fused in (False, True):
+        got = ctx.complete(x, api.make_params(max_fill_iters=2, force_fused=fused), allow_not_converged=True)
+        assert ctx.last_status == L.E_NOT_CONVERGED
+        assert_bit_equal(got, want, f"capped loop fused={fused}")
     with pytest.raises(api.DcmtError):
         ctx.complete(x, api.make_params(max_fill_iters=2))
 
@@ -75,9 +80,10 @@ def test_stage_parity_full_size_vs_oracle(ctx, O, golden_meta):
     for rows, cols, seed in [(352, 1216, 0), (375, 1242, 1)]:
         x = synth.synth_frame(rows, cols, seed)
         for st in (4, 5, 6, 7, 9, 11):
-            got = ctx.complete(x, api.make_params(stop_after=st))
             want = O.img_completion(x, O.default_params(stop_after=st))
-            assert_bit_equal(got, want, f"{rows}x{cols} stage {st}")
+            assert_bit_equal(ctx.complete(x, api.make_params(stop_after=st)), want, f"{rows}x{cols} stage {st}")
+            if st >= 6:
+                assert_bit_equal(ctx.complete(x, api.make_params(stop_after=st, force_fused=True)), want, f"{rows}x{cols} fused stage {st}")
         m = golden_meta["full"][f"{rows}x{cols}_seed{seed}"]
         assert sha(ctx.complete(x)) == m["out_sha256"]
         assert ctx.last_fill_iters(1)[0][0] == m["fill_iters"]
@@ -233,13 +239,13 @@ def test_fused_path_odd_sizes_and_presets(ctx, O):
         x[rng.integers(0, rows, 5), rng.integers(0, cols, 5)] = 30.0      # something valid even in tiny frames
         for k0 in ("as_compiled", "diamond"):
             want = O.img_completion(x, O.default_params(k0=k0))
-            assert_bit_equal(ctx.complete(x, api.make_params(k0=k0)), want, f"fused {rows}x{cols} {k0}")
+            assert_bit_equal(ctx.complete(x, api.make_params(k0=k0, force_fused=True)), want, f"fused {rows}x{cols} {k0}")
             assert_bit_equal(ctx.complete(x, api.make_params(k0=k0, force_staged=True)), want, f"staged {rows}x{cols} {k0}")
     x = synth.synth_frame(352, 1216, 77)
-    assert_bit_equal(ctx.complete(x, api.make_params(k0="diamond")), O.img_completion(x, O.default_params(k0="diamond")), "diamond full size")
-    assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none")), O.img_completion(x, O.default_params(blur="none")), "no blur full size")
+    assert_bit_equal(ctx.complete(x, api.make_params(k0="diamond", force_fused=True)), O.img_completion(x, O.default_params(k0="diamond")), "diamond full size")
+    assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none", force_fused=True)), O.img_completion(x, O.default_params(blur="none")), "no blur full size")
     for st in (6, 7, 8, 9, 10):
-        assert_bit_equal(ctx.complete(x, api.make_params(stop_after=st)), O.img_completion(x, O.default_params(stop_after=st)), f"fused stage {st}")
+        assert_bit_equal(ctx.complete(x, api.make_params(stop_after=st, force_fused=True)), O.img_completion(x, O.default_params(stop_after=st)), f"fused stage {st}")
 
 
 def test_dense_and_adversarial_values_full_size(ctx, O):
@@ -247,7 +253,8 @@ def test_dense_and_adversarial_values_full_size(ctx, O):
     x = rng.uniform(0.0, 130.0, size=(352, 1216)).astype(np.float32)     # dense, incl. depths beyond max_depth
     x[rng.random(x.shape) < 0.3] = 0
     x[100:140, 300:420] = 0                                               # a 40 x 120 hole: needs the loop
-    got = ctx.complete(x)
     want, info = O.img_completion(x, return_info=True)
-    assert_bit_equal(got, want, "dense random")
-    assert ctx.last_fill_iters(1)[0][0] == info["fill_iters"]
+    for fused in (False, True):
+        got = ctx.complete(x, api.make_params(force_fused=fused))
+        assert_bit_equal(got, want, f"dense random fused={fused}")
+        assert ctx.last_fill_iters(1)[0][0] == info["fill_iters"]
