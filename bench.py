@@ -175,7 +175,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "gpu_ms_per_step": gpu_ms_per_step, "algorithmic_bytes_per_step": B * BYTES_PER_FRAME,
-                         "kernel": "whole cascade (k_init + k_pre + k_fill31 x2 + k_post), HIP events around each step"},
+                         "kernel": "whole cascade per step = k_pre_s + k_fp_s (+ 3 skipped redo launches), HIP events around each step on the launch stream; per-kernel times in profiles/"},
             "fill_iters_max": max(iters),
         }
         line.update(extra)

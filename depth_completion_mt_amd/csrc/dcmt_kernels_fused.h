@@ -283,7 +283,20 @@ struct PostS {
 #define DCMT_CX(a, b)   { const float lo_ = fmin2(v[a], v[b]); v[b] = fmax2(v[a], v[b]); v[a] = lo_; }
 #define DCMT_CMIN(a, b) { v[a] = fmin2(v[a], v[b]); }
 #define DCMT_CMAX(a, b) { v[b] = fmax2(v[a], v[b]); }
-__device__ __forceinline__ void sort5(float (&v)[5]) { DCMT_SORT5_NET(DCMT_CX, DCMT_CMIN, DCMT_CMAX) }
+// sort5 in 12 three-input instructions instead of a 9-exchange network's 18 (min/max/med3 all issue
+// at the same rate): sort a triple (min3, med3, max3) and a pair, then merge them in closed form.
+// Verified against sorted() on all 5^5 value patterns (ties included).
+__device__ __forceinline__ void sort5(float (&v)[5])
+{
+    const float x0 = fmin3(v[0], v[1], v[2]), x1 = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]), x2 = fmax3(v[0], v[1], v[2]);
+    const float y0 = fmin2(v[3], v[4]), y1 = fmax2(v[3], v[4]);
+    const float A = fmax2(x0, y0), B = fmin2(x2, y1);
+    v[0] = fmin2(x0, y0);
+    v[1] = fmin3(A, x1, y1);
+    v[2] = __builtin_amdgcn_fmed3f(A, x1, B);
+    v[3] = fmax3(B, x1, y0);
+    v[4] = fmax2(x2, y1);
+}
 // P = merge of two sorted 5-lists
 __device__ __forceinline__ void merge55(const float (&a)[5], const float (&b)[5], float (&P)[10])
 {
@@ -563,17 +576,13 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
                 const float v = XC[(p + 1) & 15];                    // virtual row (t-15) - 15 ... see below
                 const bool hole = v < thr;                           // LO :140 / :154
                 const float r = hole ? d : v;
-                if (outlane) {
-                    op[(size_t)o * cols] = r;
-                    before += hole;
-                    after += r < thr;
-                }
+                if (outlane) op[(size_t)o * cols] = r;
+                before += __builtin_popcountll(__ballot(hole && outlane));
+                after += __builtin_popcountll(__ballot(r < thr && outlane));
             }
         }
     }
-    // hole counts of this strip
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) { before += __shfl_xor(before, sh, 64); after += __shfl_xor(after, sh, 64); }
+    // hole counts of this strip (accumulated on the scalar unit)
     if (lane == 0 && !redo) {                     // a redo recomputes what k_fp_s already counted
         if (app == 0 && before) atomicAdd(&cnt[0], before);
         if (after) atomicAdd(&cnt[1 + app], after);
@@ -588,9 +597,9 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
 // register per lane ("B"): lanes 0..14 hold the 15 columns right of the strip, lanes 49..63
 // the 15 columns left of it, so that both are whole 16-lane DPP rows and the same
 // prefix / suffix row scans apply.  With M = max(P, S) of the lane's own 16-block:
-//     out(c) = max( S'((c - 15) mod 64), M(c), P'((c + 15) mod 64) ),
-//     S' = lane >= 49 ? S_B : S_A,   P' = lane <= 14 ? P_B : P_A
-// -- the wrap-around of the two ds_bpermutes lands exactly on the B lanes.  Every one of the 64
+//     out(c) = max( S'(c >= 15 ? c - 15 : 63 - c), M(c), P'((c + 15) mod 64) ),
+//     S' = lane >= 49 ? P_B : S_A,   P' = lane <= 14 ? P_B : P_A
+// -- the left halo sits in B in descending column order, so both halos need the same prefix scan.  Every one of the 64
 // lanes therefore gets its exact X7 value, and the post pipeline (PostPipe) runs on it in the
 // same step, 32 steps later than the fill front end (30 rows of fill latency + its own 2 rows
 // of replicate padding): step t feeds X7 row clamp(t - 34) to post step u = t - 32.
@@ -625,17 +634,20 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     const size_t fo = (size_t)f * rows * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
     const int gxa = gx0 + lane;
-    const int gxb = lane <= 14 ? gx0 + 64 + lane : (lane >= 49 ? gx0 - 64 + lane : gxa);
+    // B: lanes 0..14 = the 15 columns right of the strip (ascending); lanes 49..63 = the 15 columns left of it
+    // in DESCENDING order (lane 49 = gx0-1 ... lane 63 = gx0-15; lane 48 duplicates gx0-1), so that the
+    // suffix the left side needs is a PREFIX over lanes too and one row scan serves both halos
+    const int gxb = lane <= 14 ? gx0 + 64 + lane : (lane >= 49 ? gx0 + 48 - lane : (lane == 48 ? gx0 - 1 : gxa));
     const float* spa = x6 + fo + min(max(gxa, 0), cols - 1);       // clamped: replicate == constant border for a max filter
     const float* spb = x6 + fo + min(max(gxb, 0), cols - 1);
     const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
     const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
     const int src_lane = min(max(gxa, 0), cols - 1) - gx0;          // BORDER_REPLICATE columns for the median
-    const int a_lo = ((lane - 15) & 63) * 4, a_hi = ((lane + 15) & 63) * 4;
+    const int a_lo = (lane < 15 ? 63 - lane : lane - 15) * 4, a_hi = ((lane + 15) & 63) * 4;   // ds_bpermute byte addresses
     float (*dl_c)[64] = reinterpret_cast<float (*)[64]>(s_delay[wave]);
     float (*dl_a)[64] = reinterpret_cast<float (*)[64]>(s_delay[wave] + 16 * 64);
     float (*dl_b)[32] = reinterpret_cast<float (*)[32]>(s_delay[wave] + 16 * 128);
-    const int lb = lane <= 14 ? lane : (lane >= 49 ? lane - 32 : 15 + (lane & 1));   // B's live lanes 0..14, 49..63 -> 0..14, 17..31; the rest share two junk words
+    const int lb = lane <= 14 ? lane : (lane >= 48 ? lane - 32 : 15);   // B's live lanes 0..14, 48..63 -> words 0..14, 16..31; the dead lanes share word 15
 
     PostPipe<11, BLUR> pipe;
     pipe.init(dst + fo + min(max(gxa, 0), cols - 1), rows, cols, gx0, lane, max_depth, thr);
@@ -675,7 +687,10 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         const bool hole = pend_v < thr;                             // LO :140
         float x7 = hole ? d : pend_v;
         const int o = t - 31;
-        if ((unsigned)o < (unsigned)rows && own) { before += hole; after += x7 < thr; }
+        if ((unsigned)o < (unsigned)rows) {                         // hole counts on the scalar unit: ballot + s_bcnt1
+            before += __builtin_popcountll(__ballot(hole && own));
+            after += __builtin_popcountll(__ballot(x7 < thr && own));
+        }
         if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
         if (o == 0) x7_first = x7;
         if (o == rows - 1) x7_last = x7;
@@ -700,8 +715,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         const float w31a = fmax2(w16a, w16a_old), w31b = fmax2(w16b, w16b_old);
         // horizontal 31-max: scans now, the cross-row fetches land during the next step
         const float PA = row_prefix_max(w31a), SA = row_suffix_max(w31a);
-        const float PB = row_prefix_max(w31b), SB = row_suffix_max(w31b);
-        const float Sm = lane >= 49 ? SB : SA, Pm = lane <= 14 ? PB : PA;
+        const float PB = row_prefix_max(w31b);
+        const float Sm = lane >= 49 ? PB : SA, Pm = lane <= 14 ? PB : PA;   // lane 48 of S' is still S_A(48), needed by c = 63
         pend_slo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_lo, __builtin_bit_cast(int, Sm)));
         pend_phi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_hi, __builtin_bit_cast(int, Pm)));
         pend_m = fmax2(PA, SA);
@@ -730,8 +745,6 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             pipe.template step<(p & 7)>(xin, u);
         });
     }
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) { before += __shfl_xor(before, sh, 64); after += __shfl_xor(after, sh, 64); }
     if (lane == 0) {
         if (before) atomicAdd(&cnt[0], before);
         if (after) atomicAdd(&cnt[1], after);
