@@ -185,8 +185,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
         for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(q, rows - 1) * cols];
     }
 
-    int ti = -1, bi = -1;                        // first / last valid row of X5 in this lane's column
-    float tv = 0.f, bv = 0.f;
+    int ti = 0x7fffffff, bi = -1;                // first / last valid row of X5 in this lane's column
 
     const int nsteps = rows + G::LAT;
     for (int i0 = 0; i0 < nsteps; i0 += 8) {
@@ -243,19 +242,21 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
             const float e = E4[(p + 7) & 7];                             // row m = i-9
             const float x5 = e < thr ? d7 : e;
             if ((unsigned)m < (unsigned)rows) {
-                // ---- H6 bookkeeping (LO :112-121): first / last row with x > 0.1
-                if (x5 >= thr) {
-                    if (ti < 0) { ti = m; tv = x5; }
-                    bi = m; bv = x5;
-                }
+                // ---- H6 bookkeeping (LO :112-121): first / last row with x > 0.1 (their values are re-read
+                // from the rows stored below, in the epilogue)
+                const bool valid = x5 >= thr;
+                ti = min(ti, valid ? m : 0x7fffffff);
+                bi = valid ? m : bi;
                 // rows above the first valid one are written by the epilogue
-                if (outlane && ti >= 0) op[(size_t)m * cols] = x5;
+                if (outlane && m >= ti) op[(size_t)m * cols] = x5;
             }
         }
     }
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
     // value; a column without valid pixels ends as 100 everywhere (:110, :125-127)
-    if (ti < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's own stores, before it reads two of them back
+    float tv = op[(size_t)min(ti, rows - 1) * cols], bv = op[(size_t)max(bi, 0) * cols];
+    if (bi < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
     if (!outlane) { ti = -1; bi = rows; }
     const int tmax = wave_max_i(ti);
     for (int r = 0; r <= tmax; ++r)
@@ -740,7 +741,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             const int t = t0 + p, u = t - FpS::LAG;
             DL[p & 7] = fill_step(P_, t);
             float xin = DL[(p + 5) & 7];
-            if (u < 2) xin = x7_first;
+            if (u < 2) xin = x7_first;                              // replicated rows
             if (u - 2 >= rows) xin = x7_last;
             pipe.template step<(p & 7)>(xin, u);
         });

@@ -9,6 +9,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
     float a = threadIdx.x * 0.5f, b = threadIdx.x * 0.25f + 1.f, c = 3.f, d = 4.f;
     const unsigned long long msk = 0x5555555555555555ull ^ (unsigned long long)blockIdx.x;
     const int mv = (threadIdx.x * 4) & 255;
+    unsigned sc = blockIdx.x;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -27,10 +28,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
             if (MODE == 12) { asm volatile("v_cmp_ge_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_ge_f32 vcc, %2, %3\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "vcc"); }
             if (MODE == 13) { asm volatile("ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(mv)); }
             if (MODE == 14) { asm volatile("v_pk_max_f16 %0, %0, %1\n v_pk_max_f16 %1, %1, %2\n v_pk_max_f16 %2, %2, %3\n v_pk_max_f16 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 16) { asm volatile("v_max_f32 %0, %0, %1\n s_nop 0\n v_max_f32 %1, %1, %2\n s_nop 0\n v_max_f32 %2, %2, %3\n s_nop 0\n v_max_f32 %3, %3, %0\n s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 17) { asm volatile("v_max_f32 %0, %0, %1\n s_add_u32 %4, %4, 1\n v_max_f32 %1, %1, %2\n s_add_u32 %4, %4, 3\n v_max_f32 %2, %2, %3\n s_mul_i32 %4, %4, 5\n v_max_f32 %3, %3, %0\n s_add_u32 %4, %4, 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(sc)); }
+            if (MODE == 18) { asm volatile("v_max_f32 %0, %0, %1\n s_nop 1\n v_max_f32_dpp %1, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_max_f32_dpp %2, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_max_f32_dpp %3, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 19) { asm volatile("v_max_f32 %0, %0, %1\n v_max_f32 %0, %0, %2\n v_max_f32 %0, %0, %3\n v_max_f32 %0, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
             if (MODE == 15) { asm volatile("v_max_u32 %0, %0, %1\n v_max_i32 %1, %1, %2\n v_min_u32 %2, %2, %3\n v_min_i32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;
+    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + (float)sc;
 }
 
 template <int MODE> void run(const char* name, float* d)
@@ -66,5 +71,9 @@ int main()
     run<13>("ds_bpermute_b32", d);
     run<14>("v_pk_max_f16", d);
     run<15>("v_max/min_u32/i32", d);
+    run<16>("v_max + s_nop 0 alternating", d);
+    run<17>("v_max + SALU alternating", d);
+    run<18>("dependent DPP chain + s_nop 1", d);
+    run<19>("dependent v_max chain", d);
     return 0;
 }
