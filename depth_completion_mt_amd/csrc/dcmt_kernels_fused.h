@@ -714,13 +714,17 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         dl_a[p][lane] = w16a;
         dl_b[p][lb] = w16b;
         const float w31a = fmax2(w16a, w16a_old), w31b = fmax2(w16b, w16b_old);
-        // horizontal 31-max: scans now, the cross-row fetches land during the next step
-        const float PA = row_prefix_max(w31a), SA = row_suffix_max(w31a);
-        const float PB = row_prefix_max(w31b);
-        const float Sm = lane >= 49 ? PB : SA, Pm = lane <= 14 ? PB : PA;   // lane 48 of S' is still S_A(48), needed by c = 63
-        pend_slo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_lo, __builtin_bit_cast(int, Sm)));
-        pend_phi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_hi, __builtin_bit_cast(int, Pm)));
-        pend_m = fmax2(PA, SA);
+        // horizontal 31-max: scans now, the cross-row fetches land during the next step.  The fill only
+        // replaces holes (x < thr), so a row in which none of this wave's 64 columns is a hole needs no
+        // horizontal maximum at all (wave-uniform skip; the vertical state above is always kept current).
+        if (__ballot(v < thr) != 0ull) {
+            const float PA = row_prefix_max(w31a), SA = row_suffix_max(w31a);
+            const float PB = row_prefix_max(w31b);
+            const float Sm = lane >= 49 ? PB : SA, Pm = lane <= 14 ? PB : PA;   // lane 48 of S' is still S_A(48), needed by c = 63
+            pend_slo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_lo, __builtin_bit_cast(int, Sm)));
+            pend_phi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_hi, __builtin_bit_cast(int, Pm)));
+            pend_m = fmax2(PA, SA);
+        }
         pend_v = v;
         return x7;
     };
