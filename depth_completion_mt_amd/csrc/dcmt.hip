@@ -45,7 +45,7 @@ struct dcmt_ctx {
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
     int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
     int fuse_fp = 1;                  // H7..H11 in one kernel (k_fp_s); env DCMT_FUSE_FP=0 keeps k_fill_s + k_post_s
-    int min_fused_batch = 4;          // smaller batches use the staged kernels; env DCMT_MIN_FUSED_BATCH
+    int min_fused_batch = 12;         // smaller batches use the staged kernels (measured crossover: tools/batch_sweep.py); env DCMT_MIN_FUSED_BATCH
 };
 
 namespace {

@@ -110,14 +110,16 @@ def test_device_entry_point_batch(ctx, O):
     frames[2] = 0                                   # an empty frame in the middle of the batch
     frames[4, :, 100:140] = 0                       # empty columns
     d = torch.from_numpy(frames).cuda()
-    out = ctx.complete_dev(d)
-    torch.cuda.synchronize()
-    got = out.cpu().numpy()
-    for i in range(frames.shape[0]):
-        assert_bit_equal(got[i], O.img_completion(frames[i]), f"device batch frame {i}")
-    iters, st = ctx.last_fill_iters(6)
-    assert st == L.OK and iters == [1] * 6
-    assert (got[2] == 0).all()
+    want = [O.img_completion(frames[i]) for i in range(frames.shape[0])]
+    for fused in (True, False):                     # 6 frames: the default picks the staged kernels, force the streaming ones too
+        out = ctx.complete_dev(d, params=api.make_params(force_fused=fused))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(frames.shape[0]):
+            assert_bit_equal(got[i], want[i], f"device batch frame {i} fused={fused}")
+        iters, st = ctx.last_fill_iters(6)
+        assert st == L.OK and iters == [1] * 6
+        assert (got[2] == 0).all()
     # a non-default stream
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -137,13 +139,14 @@ def test_device_entry_point_speculative_loop(ctx, golden, O):
     import torch
     x = golden["adv_tall_gap_in"]
     d = torch.from_numpy(x[None].copy()).cuda()
-    ctx.complete_dev(d, params=api.make_params(spec_fill_iters=1))
-    iters, st = ctx.last_fill_iters(1)
-    assert st == L.E_NOT_CONVERGED and iters == [-1]
-    out = ctx.complete_dev(d, params=api.make_params(spec_fill_iters=8))
-    iters, st = ctx.last_fill_iters(1)
-    assert st == L.OK and iters == [7]
-    assert_bit_equal(out.cpu().numpy()[0], O.img_completion(x), "speculative loop")
+    for fused in (False, True):
+        ctx.complete_dev(d, params=api.make_params(spec_fill_iters=1, force_fused=fused))
+        iters, st = ctx.last_fill_iters(1)
+        assert st == L.E_NOT_CONVERGED and iters == [-1]
+        out = ctx.complete_dev(d, params=api.make_params(spec_fill_iters=8, force_fused=fused))
+        iters, st = ctx.last_fill_iters(1)
+        assert st == L.OK and iters == [7]
+        assert_bit_equal(out.cpu().numpy()[0], O.img_completion(x), f"speculative loop fused={fused}")
 
 
 def test_strided_host_input_and_output_independence(ctx, O):
