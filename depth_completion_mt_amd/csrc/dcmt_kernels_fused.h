@@ -642,6 +642,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     const float* spa = x6 + fo + min(max(gxa, 0), cols - 1);       // clamped: replicate == constant border for a max filter
     const float* spb = x6 + fo + min(max(gxb, 0), cols - 1);
     const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
+    const unsigned long long own_mask = __ballot(own);          // wave-uniform: the hole counts stay on the scalar unit
     const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
     const int src_lane = min(max(gxa, 0), cols - 1) - gx0;          // BORDER_REPLICATE columns for the median
     const int a_lo = (lane < 15 ? 63 - lane : lane - 15) * 4, a_hi = ((lane + 15) & 63) * 4;   // ds_bpermute byte addresses
@@ -689,8 +690,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         float x7 = hole ? d : pend_v;
         const int o = t - 31;
         if ((unsigned)o < (unsigned)rows) {                         // hole counts on the scalar unit: ballot + s_bcnt1
-            before += __builtin_popcountll(__ballot(hole && own));
-            after += __builtin_popcountll(__ballot(x7 < thr && own));
+            before += __builtin_popcountll(__ballot(hole) & own_mask);
+            after += __builtin_popcountll(__ballot(x7 < thr) & own_mask);
         }
         if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
         if (o == 0) x7_first = x7;

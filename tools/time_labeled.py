@@ -1,0 +1,20 @@
+"""frames/s of the label-masked variant (BASELINE configs 3 and 4) on device-resident batches."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from depth_completion_mt_amd import Context, make_params, synth
+for rows, cols, nt, B in ((352, 1216, 1200, 64), (375, 1242, 100, 64)):
+    lab, nl = synth.synth_labels(rows, cols, nt, 0)
+    d = torch.from_numpy(synth.synth_batch(8, rows, cols, 0)).cuda().repeat(B // 8, 1, 1).contiguous()
+    dl = torch.from_numpy(lab).cuda()[None].repeat(B, 1, 1).contiguous()
+    o = torch.empty_like(d)
+    ctx = Context(0, rows, cols, B)
+    p = make_params()
+    for _ in range(2): ctx.complete_dev(d, o, p, d_labels=dl, n_labels=nl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); n = 5
+    for _ in range(n): ctx.complete_dev(d, o, p, d_labels=dl, n_labels=nl)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"labeled {cols}x{rows}, {nl} labels, batch {B}: {B * n / dt:.0f} frames/s ({dt / n * 1e3:.2f} ms per batch)")
+    ctx.close()
