@@ -138,17 +138,24 @@ def main():
 
     extra = {}
     if args.batch1 and rank == 0:
-        ctx1 = Context(local_rank, ROWS, COLS, 1)
-        n1 = 300
-        for i in range(20):
-            ctx1.complete_dev(d_src[i % B], d_dst[i % B], params, stream=stream.cuda_stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n1):
-            ctx1.complete_dev(d_src[i % B], d_dst[i % B], params, stream=stream.cuda_stream)
-        torch.cuda.synchronize()
-        extra["batch1_streamed_frames_per_s"] = n1 / (time.perf_counter() - t1)
-        ctx1.close()
+        # BASELINE configs[1]: frames arrive one at a time (batch = 1 per call).  One context + stream per
+        # in-flight frame; independent frames overlap on the GPU, each call is still a whole cascade on one frame.
+        n1 = 400
+        for nstreams in (1, 4):
+            ctxs = [Context(local_rank, ROWS, COLS, 1) for _ in range(nstreams)]
+            streams = [torch.cuda.Stream() for _ in range(nstreams)]
+            def run(n):
+                for i in range(n):
+                    k = i % nstreams
+                    ctxs[k].complete_dev(d_src[i % B], d_dst[i % B], params, stream=streams[k].cuda_stream)
+            run(4 * nstreams)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(n1)
+            torch.cuda.synchronize()
+            extra["batch1_streamed_frames_per_s" if nstreams == 1 else f"batch1_streamed_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
+            for c in ctxs:
+                c.close()
 
     if rank == 0:
         frames_total = B * world * args.steps
