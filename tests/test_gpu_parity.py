@@ -261,3 +261,28 @@ def test_dense_and_adversarial_values_full_size(ctx, O):
         got = ctx.complete(x, api.make_params(force_fused=fused))
         assert_bit_equal(got, want, f"dense random fused={fused}")
         assert ctx.last_fill_iters(1)[0][0] == info["fill_iters"]
+
+
+def test_dispatch_toggles_give_identical_results(O):
+    """The environment toggles of the fused path (separate k_fill_s + k_post_s instead of k_fp_s, dword row
+    loads instead of the LDS-DMA ring, plain instead of XCD-aware block mapping) only pick other kernels for
+    the same arithmetic: every combination must reproduce the oracle.  Run in a child process each, because
+    the toggles are read when a context is created."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from depth_completion_mt_amd import Context, make_params, synth
+        from oracle import oracle as O
+        frames = synth.synth_batch(16, 352, 1216, 500)
+        frames[3, 120:170, 400:520] = 0            # needs the hole-closure loop: exercises the redo path
+        with Context(0, 352, 1216, 16) as ctx:
+            got = ctx.complete(frames, make_params())
+        for i in (0, 3, 15):
+            assert np.array_equal(got[i].view(np.uint32), O.img_completion(frames[i]).view(np.uint32)), i
+        print("OK")
+    """)
+    for env in ({"DCMT_FUSE_FP": "0"}, {"DCMT_WIDE": "0"}, {"DCMT_XCD_MAP": "0"}, {"DCMT_FUSE_FP": "0", "DCMT_WIDE": "0", "DCMT_XCD_MAP": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
