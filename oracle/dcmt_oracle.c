@@ -175,8 +175,12 @@ void dcmt_oracle_extend_columns(float *x, int rows, int cols)
 }
 
 /* ---- H9: cv::medianBlur(x, x, 5) on CV_32F (LO/img_completion.cpp:170) -------------
- * exact median of the 5x5 window, BORDER_REPLICATE, behaves out of place. */
-void dcmt_oracle_median5(const float *src, float *dst, int rows, int cols)
+ * exact median of the 5x5 window, BORDER_REPLICATE, behaves out of place.
+ * dcmt_oracle_median5_simple is the definition (gather 25, select the 13th); dcmt_oracle_median5
+ * is what the chain and the CPU baseline use: the same exact median through min/max networks
+ * applied to whole rows (gcc vectorises the loops), so that the baseline is not dominated by a
+ * scalar selection sort.  The two are compared bit for bit in tests/test_oracle.py. */
+void dcmt_oracle_median5_simple(const float *src, float *dst, int rows, int cols)
 {
     for (int r = 0; r < rows; ++r)
         for (int c = 0; c < cols; ++c) {
@@ -197,6 +201,74 @@ void dcmt_oracle_median5(const float *src, float *dst, int rows, int cols)
             }
             dst[(long)r * cols + c] = w[12];
         }
+}
+
+/* compare-exchange of two rows, element by element */
+static void cx_rows(float *lo, float *hi, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        const float a = lo[i], b = hi[i];
+        lo[i] = fmin_cv(a, b);
+        hi[i] = fmax_cv(a, b);
+    }
+}
+
+#include "../tools/median_shared_nets.h"
+
+void dcmt_oracle_median5(const float *src, float *dst, int rows, int cols)
+{
+    /* S[k][r] = k-th smallest of the 5 horizontal (column-replicated) neighbours of every pixel of row r */
+    const size_t plane = (size_t)rows * cols;
+    float *S = (float *)malloc(sizeof(float) * plane * 5);
+    float *w = (float *)malloc(sizeof(float) * (size_t)cols * 20);   /* 20 work rows */
+    float *v[20];
+    for (int k = 0; k < 20; ++k) v[k] = w + (size_t)k * cols;
+#define ROWCX(a, b) cx_rows(v[a], v[b], cols);
+    for (int r = 0; r < rows; ++r) {
+        const float *s = src + (size_t)r * cols;
+        for (int k = 0; k < 5; ++k)
+            for (int c = 0; c < cols; ++c) {
+                int cc = c + k - 2; cc = cc < 0 ? 0 : (cc >= cols ? cols - 1 : cc);
+                v[k][c] = s[cc];
+            }
+        DCMT_SORT5_NET(ROWCX, ROWCX, ROWCX)
+        for (int k = 0; k < 5; ++k) memcpy(S + plane * k + (size_t)r * cols, v[k], sizeof(float) * cols);
+    }
+    /* window of output row j = rows j-2..j+2 (row-replicated): merge two pairs of sorted rows, take the six
+     * middle order statistics of those 20 values, then the 6th smallest of them and the fifth row
+     * (tools/gen_median_shared.py explains and verifies the scheme) */
+    static const int m55[10] = DCMT_MERGE55_OUT;
+    static const int mid[6] = DCMT_MID20_OUT;
+    float *P = (float *)malloc(sizeof(float) * (size_t)cols * 20);
+    for (int j = 0; j < rows; ++j) {
+        int rr[5];
+        for (int k = 0; k < 5; ++k) { int r = j + k - 2; rr[k] = r < 0 ? 0 : (r >= rows ? rows - 1 : r); }
+        for (int half = 0; half < 2; ++half) {                 /* pairs (rr[0],rr[1]) and (rr[2],rr[3]) */
+            for (int k = 0; k < 5; ++k) {
+                memcpy(v[k], S + plane * k + (size_t)rr[2 * half] * cols, sizeof(float) * cols);
+                memcpy(v[5 + k], S + plane * k + (size_t)rr[2 * half + 1] * cols, sizeof(float) * cols);
+            }
+            DCMT_MERGE55_NET(ROWCX, ROWCX, ROWCX)
+            for (int k = 0; k < 10; ++k) memcpy(P + (size_t)(10 * half + k) * cols, v[m55[k]], sizeof(float) * cols);
+        }
+        memcpy(w, P, sizeof(float) * (size_t)cols * 20);
+        DCMT_MID20_NET(ROWCX, ROWCX, ROWCX)
+        const float *a[5], *C[6];
+        for (int k = 0; k < 5; ++k) a[k] = S + plane * k + (size_t)rr[4] * cols;
+        for (int k = 0; k < 6; ++k) C[k] = v[mid[k]];
+        float *d = dst + (size_t)j * cols;
+        for (int c = 0; c < cols; ++c) {
+            float m = C[5][c];
+            m = fmin_cv(m, fmax_cv(a[0][c], C[4][c]));
+            m = fmin_cv(m, fmax_cv(a[1][c], C[3][c]));
+            m = fmin_cv(m, fmax_cv(a[2][c], C[2][c]));
+            m = fmin_cv(m, fmax_cv(a[3][c], C[1][c]));
+            m = fmin_cv(m, fmax_cv(a[4][c], C[0][c]));
+            d[c] = m;
+        }
+    }
+#undef ROWCX
+    free(P); free(w); free(S);
 }
 
 /* ---- H10: cv::GaussianBlur(s, s, Size(5,5), 0) (LO/img_completion.cpp:179) ---------

@@ -73,7 +73,7 @@ def lib(native: bool = False) -> ctypes.CDLL:
                   "dcmt_oracle_dilate_rect_bruteforce", "dcmt_oracle_erode_rect_bruteforce"):
             getattr(L, n).argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
             getattr(L, n).restype = None
-        for n in ("dcmt_oracle_median5", "dcmt_oracle_gaussian5"):
+        for n in ("dcmt_oracle_median5", "dcmt_oracle_median5_simple", "dcmt_oracle_gaussian5"):
             getattr(L, n).argtypes = [fp, fp, ctypes.c_int, ctypes.c_int]
             getattr(L, n).restype = None
         L.dcmt_oracle_extend_columns.argtypes = [fp, ctypes.c_int, ctypes.c_int]
@@ -184,8 +184,8 @@ def erode_rect(a, ksize, bruteforce=False):
     return _unary("dcmt_oracle_erode_rect" + ("_bruteforce" if bruteforce else ""), a, int(ksize))
 
 
-def median5(a):
-    return _unary("dcmt_oracle_median5", a)
+def median5(a, simple=False):
+    return _unary("dcmt_oracle_median5_simple" if simple else "dcmt_oracle_median5", a)
 
 
 def gaussian5(a):

@@ -138,6 +138,7 @@ def test_separable_equals_bruteforce():
             assert_bit_equal(O.erode_rect(a, k), O.erode_rect(a, k, bruteforce=True), f"erode {k} {shape}")
             assert_bit_equal(O.dilate_rect(a, k), N.dilate(a, np.ones((k, k), np.uint8)), f"np dilate {k}")
         assert_bit_equal(O.median5(a), N.median5(a), f"median {shape}")
+        assert_bit_equal(O.median5(a, simple=True), N.median5(a), f"median simple {shape}")
         assert_bit_equal(O.gaussian5(a), N.gaussian5(a), f"gauss {shape}")
         assert_bit_equal(O.dilate_mask5(a, N.K0_AS_COMPILED), N.dilate(a, N.K0_AS_COMPILED), "mask dilate")
         assert_bit_equal(O.dilate_mask5(a, N.K0_DIAMOND), N.dilate(a, N.K0_DIAMOND), "diamond dilate")
