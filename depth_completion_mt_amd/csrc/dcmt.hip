@@ -45,6 +45,9 @@ struct dcmt_ctx {
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
     int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
     int fuse_fp = 1;                  // H7..H11 in one kernel (k_fp_s); env DCMT_FUSE_FP=0 keeps k_fill_s + k_post_s
+    int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
+    int* bb_max = nullptr;
+    size_t bb_ints = 0;
     int min_fused_batch = 12;         // smaller batches use the staged kernels (measured crossover: tools/batch_sweep.py); env DCMT_MIN_FUSED_BATCH
 };
 
@@ -136,8 +139,9 @@ int fill_loop(dcmt_ctx* ctx, int batch, const dcmt_params* p, hipStream_t st, bo
 // Fast path: k_pre_s -> k_fill_t (-> k_fill_loop_t ...) -> k_post_s.  Preconditions checked by the caller.
 // The batch is walked in chunks of ctx->chunk frames so that a chunk's intermediates (X6, X7:
 // 2 x 1.7 MB per frame) stay resident in the 256 MiB Infinity Cache between the three kernels.
+// d_x4 != nullptr: X4 is already there (LC fast path): k_pre_s only runs H5 + H6 on it.
 int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst, int rows, int cols, int batch,
-                    const dcmt_params* p, hipStream_t st, bool sync_loop)
+                    const dcmt_params* p, hipStream_t st, bool sync_loop, const float* d_x4 = nullptr)
 {
     const int stop = p->stop_after;
     ctx->last_stream = st;
@@ -152,7 +156,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int nb = batch - f0 < chunk ? batch - f0 : chunk;
         const int xm = (ctx->xcd_map && nb % 8 == 0) ? 1 : 0;
-        const float* src = d_src + f0 * fe;
+        const float* src = (d_x4 ? d_x4 : d_src) + f0 * fe;
         float* dst = d_dst + f0 * fe;
         float* x6 = ctx->x5 + f0 * fe;
         float* pp0 = ctx->pp[0] + f0 * fe;
@@ -163,8 +167,10 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
             const bool wide = ctx->wide && cols % 4 == 0 && ((uintptr_t)src % 16 == 0);
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
-                hipLaunchKernelGGL((k_pre_s<KIND, WIDE>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols, \
-                                   strips, nb, xm, p->max_depth, p->valid_thresh); }
+                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols, \
+                                             strips, nb, xm, p->max_depth, p->valid_thresh); \
+                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols, \
+                                        strips, nb, xm, p->max_depth, p->valid_thresh); }
             if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
             else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
 #undef DCMT_PRE
@@ -256,6 +262,38 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
         // the streaming kernels give one wave a whole column strip: a handful of frames cannot fill the
         // GPU with them, there the staged tile kernels (hundreds of small workgroups per frame) win
         const bool big_enough = batch >= ctx->min_fused_batch || (p->flags & DCMT_FLAG_FORCE_FUSED);
+        if (!(p->flags & DCMT_FLAG_FORCE_STAGED) && big_enough && labeled && kind >= 0 && rows >= 8 && cols >= 8 && n_labels > 0 &&
+            (stop == DCMT_STAGE_FINAL || stop == DCMT_STAGE_CLOSE5)) {
+            // LC fast path: bounding boxes -> one wave per label (masked H2..H4) -> X4 -> the img_completion kernels
+            const size_t need = (size_t)batch * n_labels * 2;
+            if (need > ctx->bb_ints) {
+                (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);
+                ctx->bb_min = ctx->bb_max = nullptr; ctx->bb_ints = 0;
+                DCMT_HIP(ctx, hipMalloc((void**)&ctx->bb_min, sizeof(int) * need));
+                DCMT_HIP(ctx, hipMalloc((void**)&ctx->bb_max, sizeof(int) * need));
+                ctx->bb_ints = need;
+            }
+            DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_min, 0x7f, sizeof(int) * need, st));
+            DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_max, 0xff, sizeof(int) * need, st));
+            float* x4 = stop == DCMT_STAGE_CLOSE5 ? d_dst : ctx->pp[1];
+            hipLaunchKernelGGL(k_label_bbox, dim3((cols + 63) / 64, (rows + 31) / 32, batch), dim3(256), 0, st, d_src, d_labels, n_labels,
+                               ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh);
+            const dim3 lg((n_labels + 3) / 4, batch);
+            if (kind == K0_AS_COMPILED)
+                hipLaunchKernelGGL((k_label_stage_s<K0_AS_COMPILED>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max,
+                                   x4, rows, cols, p->max_depth, p->valid_thresh);
+            else
+                hipLaunchKernelGGL((k_label_stage_s<K0_DIAMOND>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max,
+                                   x4, rows, cols, p->max_depth, p->valid_thresh);
+            DCMT_HIP(ctx, hipGetLastError());
+            if (stop == DCMT_STAGE_CLOSE5) {
+                ctx->last_stream = st; ctx->last_batch = batch; ctx->last_apps_launched = 0; ctx->last_has_loop = 0;
+                return DCMT_OK;
+            }
+            dcmt_params q = *p;
+            q.blur = blur;
+            return run_chain_fused(ctx, kind, d_src, d_dst, rows, cols, batch, &q, st, sync_loop, x4);
+        }
         if (!(p->flags & DCMT_FLAG_FORCE_STAGED) && big_enough && !labeled && kind >= 0 && rows >= 8 && cols >= 8 &&
             stop >= DCMT_STAGE_EXTEND) {
             dcmt_params q = *p;
@@ -458,6 +496,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
     (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
+    (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     delete ctx;
 }

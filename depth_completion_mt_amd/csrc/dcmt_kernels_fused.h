@@ -145,12 +145,15 @@ struct PreS {
     static constexpr int LAT = 9;                // rows between the input row and the finished X5 row
 };
 
-template <int K0KIND, bool WIDE>
+// START4: the input is already X4 (the label-masked stage of the LC variant produced it): only H5 and H6
+// run; the row fed at step i is image row i - 6, so that all the ring slots below keep their meaning.
+template <int K0KIND, bool WIDE, bool START4 = false>
 __global__ __launch_bounds__(256)
 void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, int cols, int strips,
              int batch, int xcd_map, float max_depth, float thr)
 {
     using G = PreS<K0KIND, WIDE>;
+    constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
     __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * 4 * 256 : 4];   // 4 waves x 4 slots x (4 rows x 64 columns)
     const int lane = threadIdx.x & 63;
     int f, sg;
@@ -164,7 +167,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
     const int gxc = min(max(gx, 0), cols - 1);       // loads are unconditional, from clamped addresses
     const float* sp = src + fo + gxc;
     float* op = x6 + fo + gxc;
-    RowRing<4, 0> rr;
+    RowRing<4, ROFF> rr;
     if constexpr (WIDE) rr.init(s_ring + (strip & 3) * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
 
     constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
@@ -182,7 +185,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
         rr.issue(0); rr.issue(1); rr.issue(2);   // three 4-row blocks ahead
     } else {
 #pragma unroll
-        for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(q, rows - 1) * cols];
+        for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - ROFF, 0), rows - 1) * cols];
     }
 
     int ti = 0x7fffffff, bi = -1;                // first / last valid row of X5 in this lane's column
@@ -199,8 +202,13 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
                 raw = rr.read(i, lane);
             } else {
                 raw = PF[p];
-                PF[(p + PFD) & 7] = sp[(size_t)min(i + PFD, rows - 1) * cols];
+                PF[(p + PFD) & 7] = sp[(size_t)min(max(i + PFD - ROFF, 0), rows - 1) * cols];
             }
+            float e4;
+            const int l = i - 6;
+            if constexpr (START4) {
+                e4 = raw;                                               // X4 row l
+            } else {
             const float x2 = (incol && i < rows) ? invert_valid(raw, max_depth, thr) : NEG;
             // ---- H3 (LO :71-80), row j = i - 2
             const int j = i - 2;
@@ -229,8 +237,8 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
             d4 = (incol && (unsigned)k < (unsigned)rows) ? d4 : POS;     // border value of the erode
             // ---- H4 erode 5x5: row l = k - 2
             HE[(p + 4) & 7] = hgrow_min(hmin3(d4));                      // slot of row k = i-4
-            const int l = i - 6;
-            float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+            e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+            }
             e4 = (incol && (unsigned)l < (unsigned)rows) ? e4 : NEG;     // border value of the 7x7 dilate
             E4[(p + 2) & 7] = e4;                                        // slot of row l = i-6
             // ---- H5 (LO :88-100): dilate 7x7, row m = l - 3, then fill where x < 0.1
@@ -264,6 +272,124 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
     const int bmin = wave_min_i(bi);
     for (int r = bmin; r < rows; ++r)
         if (r >= bi) op[(size_t)r * cols] = bv;
+}
+
+// ---------------------------------------------------------------------------------
+// LC variant, fast path (LC/img_completion_lc.cpp:78-102): for every label c
+//     region = x * [label == c];  region = erode5(dilate5(dilate_k0(region)));  x[label == c] = region[label == c]
+// Labels are disjoint and each write-back depends only on the pre-loop values of its own label.
+//   k_label_bbox     one pass over the label plane: bounding box of every label (atomics only where a
+//                    run of equal labels starts / ends), and X4 = H2 for the pixels no label claims;
+//   k_label_stage_s  one wave64 per (frame, label): the k_pre_s pipeline (H2, H3, H4) on the masked
+//                    image over the label's bounding box grown by 6, lane = column, rows streamed;
+//                    writes X4 where label == c.  Boxes wider than 52 columns are walked in chunks.
+//   k_pre_s<START4>  H5 + H6 on X4, then k_fp_s as for img_completion.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
+                  int* __restrict__ bb_min, int* __restrict__ bb_max, float* __restrict__ x4,
+                  int rows, int cols, float max_depth, float thr)
+{
+    // grid: (column strips of 64, row blocks of 32 rows, frames); one wave walks 8 of the 32 rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.z;
+    const int gx = blockIdx.x * 64 + lane;
+    const size_t fo = (size_t)f * rows * cols;
+    int* mn = bb_min + (size_t)f * n_labels * 2;       // [label][0] = ymin, [1] = xmin   (init 0x7f7f7f7f)
+    int* mx = bb_max + (size_t)f * n_labels * 2;       // [label][0] = ymax, [1] = xmax   (init -1)
+    for (int r = 0; r < 8; ++r) {
+        const int gy = blockIdx.y * 32 + wave * 8 + r;
+        if (gy >= rows) break;
+        const bool in = gx < cols;
+        int l = in ? labels[fo + (size_t)gy * cols + gx] : -1;
+        const bool lv = in && l >= 0 && l < n_labels;
+        if (!lv) l = -1;
+        const int left = __builtin_amdgcn_update_dpp(-2, l, 0x138, 0xf, 0xf, false);   // lane 0 keeps -2: always a run start
+        const int right = __builtin_amdgcn_update_dpp(-2, l, 0x130, 0xf, 0xf, false);
+        if (lv && l != left) { atomicMin(&mn[2 * l], gy); atomicMax(&mx[2 * l], gy); atomicMin(&mn[2 * l + 1], gx); }
+        if (lv && l != right) atomicMax(&mx[2 * l + 1], gx);
+        if (in && !lv) x4[fo + (size_t)gy * cols + gx] = invert_valid(src[fo + (size_t)gy * cols + gx], max_depth, thr);
+    }
+}
+
+template <int K0KIND>
+__global__ __launch_bounds__(256)
+void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
+                     const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
+                     int rows, int cols, float max_depth, float thr)
+{
+    constexpr int H = 6, VW = 64 - 2 * H;          // reach of H3 + H4 (diamond: 6 / 6), 52 output columns per chunk
+    constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
+    const int lane = threadIdx.x & 63;
+    const int L = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (L >= n_labels) return;
+    const int f = blockIdx.y;
+    const int y0 = bb_min[((size_t)f * n_labels + L) * 2], x0 = bb_min[((size_t)f * n_labels + L) * 2 + 1];
+    const int y1 = bb_max[((size_t)f * n_labels + L) * 2], x1 = bb_max[((size_t)f * n_labels + L) * 2 + 1];
+    if (y1 < 0) return;                            // the label owns no pixel
+    const size_t fo = (size_t)f * rows * cols;
+    for (int cx = x0; cx <= x1; cx += VW) {
+        const int gx = cx - H + lane;
+        const bool incol = gx >= 0 && gx < cols;
+        const bool outlane = incol && lane >= H && lane < 64 - H && gx <= x1;
+        const int gxc = min(max(gx, 0), cols - 1);
+        const float* sp = src + fo + gxc;
+        const int32_t* lp = labels + fo + gxc;
+        float* op = x4 + fo + gxc;
+        float PF[8], XR[8], A3[8], S1[8], H4[8], HE[8];
+        int PL[8], LB[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { PF[q] = 0.f; XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; PL[q] = -1; LB[q] = -1; }
+        const int rs = y0 - H;                     // image row of step 0
+        constexpr int PFD = 4;
+#pragma unroll
+        for (int q = 0; q < PFD; ++q) {
+            const size_t ro = (size_t)min(max(rs + q, 0), rows - 1) * cols;
+            PF[q] = sp[ro]; PL[q] = lp[ro];
+        }
+        const int nsteps = y1 - y0 + 1 + 2 * H;    // the last step finishes image row y1
+        for (int s0 = 0; s0 < nsteps; s0 += 8) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int i = rs + s0 + p;           // image row fed by this step
+                const float raw = PF[p];
+                const int lab = PL[p];
+                {
+                    const size_t ro = (size_t)min(max(i + PFD, 0), rows - 1) * cols;
+                    PF[(p + PFD) & 7] = sp[ro]; PL[(p + PFD) & 7] = lp[ro];
+                }
+                LB[p] = lab;
+                // masked copy (LC :94-95): the label's pixels keep their H2 value, other image pixels are 0;
+                // outside the image the dilate border value
+                const bool inimg = incol && (unsigned)i < (unsigned)rows;
+                const float x2 = inimg ? (lab == L ? invert_valid(raw, max_depth, thr) : 0.0f) : NEG;
+                const int j = i - 2;
+                float y3;
+                if constexpr (K0KIND == K0_AS_COMPILED) {
+                    const float s1 = from_right(x2);
+                    const float s2 = from_right(s1);
+                    S1[p] = s1;
+                    y3 = fmax2(S1[(p + 5) & 7], s2);
+                } else {
+                    const float a3 = hmax3(x2);
+                    XR[p] = x2;
+                    A3[p] = a3;
+                    const float a5j = hgrow_max(A3[(p + 6) & 7]);
+                    y3 = fmax2(fmax3(XR[(p + 4) & 7], A3[(p + 5) & 7], a5j), fmax2(A3[(p + 7) & 7], x2));
+                }
+                y3 = (incol && (unsigned)j < (unsigned)rows) ? y3 : NEG;
+                H4[(p + 6) & 7] = hgrow_max(hmax3(y3));
+                const int k = i - 4;
+                float d4 = fmax3(fmax3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
+                d4 = (incol && (unsigned)k < (unsigned)rows) ? d4 : POS;
+                HE[(p + 4) & 7] = hgrow_min(hmin3(d4));
+                const int l = i - 6;
+                const float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+                // write-back only where the label is this one (LC :101)
+                if (l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) op[(size_t)l * cols] = e4;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------

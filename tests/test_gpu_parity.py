@@ -164,24 +164,45 @@ def test_strided_host_input_and_output_independence(ctx, O):
 def test_labeled_variant(ctx, golden, golden_meta, O):
     x, lab = golden["lc40x56_in"], golden["lc40x56_labels"]
     nl = golden_meta["lc40x56_n_labels"]
-    got4 = ctx.complete(x, api.make_params(stop_after=L.STAGE_CLOSE5), labels=lab, n_labels=nl)
-    assert_bit_equal(got4, golden["lc40x56_stage4"], "LC stage 4")
-    assert_bit_equal(ctx.complete(x, labels=lab, n_labels=nl), golden["lc40x56_out"], "LC out")
-    assert_bit_equal(ctx.complete(x, labels=lab, n_labels=nl, use_superpixel=0), golden["lc40x56_out_nosp"], "LC nosp")
-    # blur_type is ignored by the reference's LC function: the Gaussian always runs
-    assert_bit_equal(ctx.complete(x, api.make_params(blur_type="none"), labels=lab, n_labels=nl), golden["lc40x56_out"], "LC blur forced")
     rng = np.random.default_rng(3)
     lab2 = rng.integers(-1, 9, size=x.shape).astype(np.int32)
-    assert_bit_equal(ctx.complete(x, labels=lab2, n_labels=8), O.interpolate_with_superpixels(x, lab2, 8), "random labels")
-    # config 3 / 4 shapes
-    for rows, cols, nt, seed in [(352, 1216, 1200, 0), (375, 1242, 100, 2)]:
-        xf = synth.synth_frame(rows, cols, seed)
-        labf, nlf = synth.synth_labels(rows, cols, nt, seed)
-        got = ctx.complete(xf, labels=labf, n_labels=nlf)
-        assert_bit_equal(got, O.interpolate_with_superpixels(xf, labf, nlf), f"LC {rows}x{cols}")
+    for fused in (False, True):        # the general per-tile kernel and the per-label streaming kernels
+        mk = lambda **kw: api.make_params(force_fused=fused, **kw)
+        got4 = ctx.complete(x, mk(stop_after=L.STAGE_CLOSE5), labels=lab, n_labels=nl)
+        assert_bit_equal(got4, golden["lc40x56_stage4"], f"LC stage 4 fused={fused}")
+        assert_bit_equal(ctx.complete(x, mk(), labels=lab, n_labels=nl), golden["lc40x56_out"], f"LC out fused={fused}")
+        assert_bit_equal(ctx.complete(x, mk(), labels=lab, n_labels=nl, use_superpixel=0), golden["lc40x56_out_nosp"], "LC nosp")
+        # blur_type is ignored by the reference's LC function: the Gaussian always runs
+        assert_bit_equal(ctx.complete(x, mk(blur_type="none"), labels=lab, n_labels=nl), golden["lc40x56_out"], "LC blur forced")
+        assert_bit_equal(ctx.complete(x, mk(k0="diamond"), labels=lab, n_labels=nl),
+                         O.interpolate_with_superpixels(x, lab, nl, O.default_params(k0="diamond")), f"LC diamond fused={fused}")
+        # adversarial: every pixel its own neighbourhood of labels, some unlabeled
+        assert_bit_equal(ctx.complete(x, mk(), labels=lab2, n_labels=8), O.interpolate_with_superpixels(x, lab2, 8), f"random labels fused={fused}")
+        # config 3 / 4 shapes
+        for rows, cols, nt, seed in [(352, 1216, 1200, 0), (375, 1242, 100, 2)]:
+            xf = synth.synth_frame(rows, cols, seed)
+            labf, nlf = synth.synth_labels(rows, cols, nt, seed)
+            got = ctx.complete(xf, mk(), labels=labf, n_labels=nlf)
+            assert_bit_equal(got, O.interpolate_with_superpixels(xf, labf, nlf), f"LC {rows}x{cols} fused={fused}")
     m = golden_meta["full"]["lc_352x1216_seed0"]
     labf, nlf = synth.synth_labels(352, 1216, 1200, 0)
     assert sha(ctx.complete(synth.synth_frame(352, 1216, 0), labels=labf, n_labels=nlf)) == m["out_sha256"]
+
+
+def test_labeled_device_batch(O):
+    """Config 3 as a device-resident batch (the fast LC path by default: 16 >= 12 frames), labels differing per frame."""
+    import torch
+    n = 16
+    frames = synth.synth_batch(n, 352, 1216, 900)
+    labs = np.stack([synth.synth_labels(352, 1216, 1200, 900 + i)[0] for i in range(n)])
+    nl = synth.synth_labels(352, 1216, 1200, 900)[1]
+    labs[5][labs[5] == 17] = -1                      # a label that owns no pixel in one frame
+    with api.Context(0, 352, 1216, n) as c:
+        out = c.complete_dev(torch.from_numpy(frames).cuda(), d_labels=torch.from_numpy(labs).cuda(), n_labels=nl)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+    for i in (0, 5, 15):
+        assert_bit_equal(got[i], O.interpolate_with_superpixels(frames[i], labs[i], nl), f"LC device batch frame {i}")
 
 
 def test_errors(ctx):
