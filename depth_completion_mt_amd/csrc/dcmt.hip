@@ -276,8 +276,14 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_min, 0x7f, sizeof(int) * need, st));
             DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_max, 0xff, sizeof(int) * need, st));
             float* x4 = stop == DCMT_STAGE_CLOSE5 ? d_dst : ctx->pp[1];
-            hipLaunchKernelGGL(k_label_bbox, dim3((cols + 63) / 64, (rows + 31) / 32, batch), dim3(256), 0, st, d_src, d_labels, n_labels,
-                               ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh);
+            const dim3 bg((cols + 63) / 64, (rows + 31) / 32, batch);
+            const size_t table = sizeof(int) * 4 * (size_t)n_labels;
+            if (table <= 48 * 1024)
+                hipLaunchKernelGGL(k_label_bbox<true>, bg, dim3(256), table, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
+                                   rows, cols, p->max_depth, p->valid_thresh);
+            else
+                hipLaunchKernelGGL(k_label_bbox<false>, bg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
+                                   rows, cols, p->max_depth, p->valid_thresh);
             const dim3 lg((n_labels + 3) / 4, batch);
             if (kind == K0_AS_COMPILED)
                 hipLaunchKernelGGL((k_label_stage_s<K0_AS_COMPILED>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max,

@@ -285,18 +285,28 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
 //                    writes X4 where label == c.  Boxes wider than 52 columns are walked in chunks.
 //   k_pre_s<START4>  H5 + H6 on X4, then k_fp_s as for img_completion.
 // ---------------------------------------------------------------------------------
+// LDS_TABLE: the workgroup (64 columns x 32 rows) first reduces into a per-label table in LDS (ds_min /
+// ds_max, no global traffic) and then issues global atomics only for the handful of labels it touched;
+// without it (label tables too big for LDS) every run start / end goes to global memory directly.
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(256)
 void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
                   int* __restrict__ bb_min, int* __restrict__ bb_max, float* __restrict__ x4,
                   int rows, int cols, float max_depth, float thr)
 {
-    // grid: (column strips of 64, row blocks of 32 rows, frames); one wave walks 8 of the 32 rows
+    extern __shared__ __attribute__((aligned(16))) int s_bb[];     // LDS_TABLE: [n_labels][4] = ymin, xmin, ymax, xmax
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = blockIdx.z;
     const int gx = blockIdx.x * 64 + lane;
     const size_t fo = (size_t)f * rows * cols;
     int* mn = bb_min + (size_t)f * n_labels * 2;       // [label][0] = ymin, [1] = xmin   (init 0x7f7f7f7f)
     int* mx = bb_max + (size_t)f * n_labels * 2;       // [label][0] = ymax, [1] = xmax   (init -1)
+    if constexpr (LDS_TABLE) {
+        for (int i = threadIdx.x; i < n_labels; i += 256) {
+            s_bb[4 * i] = 0x7fffffff; s_bb[4 * i + 1] = 0x7fffffff; s_bb[4 * i + 2] = -1; s_bb[4 * i + 3] = -1;
+        }
+        __syncthreads();
+    }
     for (int r = 0; r < 8; ++r) {
         const int gy = blockIdx.y * 32 + wave * 8 + r;
         if (gy >= rows) break;
@@ -306,9 +316,23 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
         if (!lv) l = -1;
         const int left = __builtin_amdgcn_update_dpp(-2, l, 0x138, 0xf, 0xf, false);   // lane 0 keeps -2: always a run start
         const int right = __builtin_amdgcn_update_dpp(-2, l, 0x130, 0xf, 0xf, false);
-        if (lv && l != left) { atomicMin(&mn[2 * l], gy); atomicMax(&mx[2 * l], gy); atomicMin(&mn[2 * l + 1], gx); }
-        if (lv && l != right) atomicMax(&mx[2 * l + 1], gx);
+        if constexpr (LDS_TABLE) {
+            if (lv && l != left) { atomicMin(&s_bb[4 * l], gy); atomicMax(&s_bb[4 * l + 2], gy); atomicMin(&s_bb[4 * l + 1], gx); }
+            if (lv && l != right) atomicMax(&s_bb[4 * l + 3], gx);
+        } else {
+            if (lv && l != left) { atomicMin(&mn[2 * l], gy); atomicMax(&mx[2 * l], gy); atomicMin(&mn[2 * l + 1], gx); }
+            if (lv && l != right) atomicMax(&mx[2 * l + 1], gx);
+        }
         if (in && !lv) x4[fo + (size_t)gy * cols + gx] = invert_valid(src[fo + (size_t)gy * cols + gx], max_depth, thr);
+    }
+    if constexpr (LDS_TABLE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_labels; i += 256) {
+            if (s_bb[4 * i + 2] >= 0) {                // touched by this workgroup
+                atomicMin(&mn[2 * i], s_bb[4 * i]); atomicMin(&mn[2 * i + 1], s_bb[4 * i + 1]);
+                atomicMax(&mx[2 * i], s_bb[4 * i + 2]); atomicMax(&mx[2 * i + 1], s_bb[4 * i + 3]);
+            }
+        }
     }
 }
 

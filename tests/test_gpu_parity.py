@@ -178,6 +178,9 @@ def test_labeled_variant(ctx, golden, golden_meta, O):
                          O.interpolate_with_superpixels(x, lab, nl, O.default_params(k0="diamond")), f"LC diamond fused={fused}")
         # adversarial: every pixel its own neighbourhood of labels, some unlabeled
         assert_bit_equal(ctx.complete(x, mk(), labels=lab2, n_labels=8), O.interpolate_with_superpixels(x, lab2, 8), f"random labels fused={fused}")
+        # more labels than the LDS bounding-box table holds (the direct global-atomic variant of the label pass)
+        lab3 = rng.integers(0, 5000, size=x.shape).astype(np.int32)
+        assert_bit_equal(ctx.complete(x, mk(), labels=lab3, n_labels=5000), O.interpolate_with_superpixels(x, lab3, 5000), f"5000 labels fused={fused}")
         # config 3 / 4 shapes
         for rows, cols, nt, seed in [(352, 1216, 1200, 0), (375, 1242, 100, 2)]:
             xf = synth.synth_frame(rows, cols, seed)

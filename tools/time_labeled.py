@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from depth_completion_mt_amd import Context, make_params, synth
-for rows, cols, nt, B in ((352, 1216, 1200, 64), (375, 1242, 100, 64)):
+for rows, cols, nt, B in ((352, 1216, 1200, 256), (375, 1242, 100, 256)):
     lab, nl = synth.synth_labels(rows, cols, nt, 0)
     d = torch.from_numpy(synth.synth_batch(8, rows, cols, 0)).cuda().repeat(B // 8, 1, 1).contiguous()
     dl = torch.from_numpy(lab).cuda()[None].repeat(B, 1, 1).contiguous()
