@@ -23,7 +23,7 @@ STAGE_FILL31, STAGE_FILLLOOP, STAGE_MEDIAN5, STAGE_BLUR, STAGE_FINAL = 7, 8, 9, 
 EXPORTS = (
     "dcmt_device_count", "dcmt_create", "dcmt_destroy", "dcmt_default_params", "dcmt_k0_as_compiled",
     "dcmt_k0_diamond", "dcmt_complete_f32", "dcmt_complete_f32_dev", "dcmt_complete_labeled_f32",
-    "dcmt_complete_labeled_f32_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
+    "dcmt_complete_labeled_f32_dev", "dcmt_complete_u16_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
     "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version",
 )
 
@@ -101,6 +101,7 @@ def lib() -> ctypes.CDLL:
         L.dcmt_complete_f32_dev.argtypes = [vp, vp, vp, i, i, i, pp, vp]
         L.dcmt_complete_labeled_f32.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, vp, sz, sz, i, i, i, pp, i]
         L.dcmt_complete_labeled_f32_dev.argtypes = [vp, vp, vp, i, vp, i, i, i, pp, i, vp]
+        L.dcmt_complete_u16_dev.argtypes = [vp, vp, ctypes.c_float, vp, i, i, i, pp, vp]
         L.dcmt_last_fill_iters.argtypes = [vp, ip, i]
         L.dcmt_last_holes_after_extend.argtypes = [vp, ip, i]
         L.dcmt_strerror.argtypes = [i]

@@ -133,6 +133,25 @@ class Context:
             raise DcmtError(st, "dcmt_complete_f32_dev")
         return d_dst
 
+    def complete_u16_dev(self, d_src16, scale: float = 1.0 / 256.0, d_dst=None, params: L.Params | None = None,
+                         stream: int | None = None):
+        """KITTI uint16 depth payload in (torch.uint16 or int16-viewed CUDA tensor [batch][rows][cols]), metres out:
+        the reference's imread + convertTo(CV_32F, 1/256) (src/DC_lidar_only/main.cpp:75-82) fused into the first kernel."""
+        import torch
+        p = params or make_params()
+        assert d_src16.is_cuda and d_src16.element_size() == 2 and d_src16.is_contiguous()
+        shp = d_src16.shape if d_src16.dim() == 3 else (1,) + tuple(d_src16.shape)
+        b, r, c = shp
+        if d_dst is None:
+            d_dst = torch.full(tuple(d_src16.shape), float("nan"), dtype=torch.float32, device=d_src16.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_src16.device).cuda_stream
+        st = L.lib().dcmt_complete_u16_dev(self._h, d_src16.data_ptr(), ctypes.c_float(scale), d_dst.data_ptr(), r, c, b,
+                                           ctypes.byref(p), ctypes.c_void_p(stream))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_complete_u16_dev")
+        return d_dst
+
     def last_fill_iters(self, n: int):
         out = (ctypes.c_int * n)()
         st = L.lib().dcmt_last_fill_iters(self._h, out, n)

@@ -141,7 +141,8 @@ int fill_loop(dcmt_ctx* ctx, int batch, const dcmt_params* p, hipStream_t st, bo
 // 2 x 1.7 MB per frame) stay resident in the 256 MiB Infinity Cache between the three kernels.
 // d_x4 != nullptr: X4 is already there (LC fast path): k_pre_s only runs H5 + H6 on it.
 int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst, int rows, int cols, int batch,
-                    const dcmt_params* p, hipStream_t st, bool sync_loop, const float* d_x4 = nullptr)
+                    const dcmt_params* p, hipStream_t st, bool sync_loop, const float* d_x4 = nullptr,
+                    const uint16_t* d_src16 = nullptr, float in_scale = 1.0f)
 {
     const int stop = p->stop_after;
     ctx->last_stream = st;
@@ -165,12 +166,15 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
             // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
-            const bool wide = ctx->wide && cols % 4 == 0 && ((uintptr_t)src % 16 == 0);
+            const bool wide = ctx->wide && cols % 4 == 0 && ((uintptr_t)src % 16 == 0) && !d_src16;
+            const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr;
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
-                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols, \
-                                             strips, nb, xm, p->max_depth, p->valid_thresh); \
-                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, src, o6, rows, cols, \
-                                        strips, nb, xm, p->max_depth, p->valid_thresh); }
+                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f); \
+                else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src16, o6, \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale); \
+                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f); }
             if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
             else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
 #undef DCMT_PRE
@@ -250,7 +254,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
 // points); otherwise enqueue p->spec_fill_iters applications speculatively.
 int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_labels, int use_superpixel,
               float* d_dst, int rows, int cols, int batch, const dcmt_params* p, bool force_gaussian,
-              hipStream_t st, bool sync_loop)
+              hipStream_t st, bool sync_loop, const uint16_t* d_src16 = nullptr, float in_scale = 1.0f)
 {
     const dim3 grid = tile_grid(rows, cols, batch), block(kThreads);
     const uint32_t kb = k0_bits(p->k0);
@@ -304,7 +308,12 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             stop >= DCMT_STAGE_EXTEND) {
             dcmt_params q = *p;
             q.blur = blur;
-            return run_chain_fused(ctx, kind, d_src, d_dst, rows, cols, batch, &q, st, sync_loop);
+            return run_chain_fused(ctx, kind, d_src, d_dst, rows, cols, batch, &q, st, sync_loop, nullptr, d_src16, in_scale);
+        }
+        if (d_src16) {   // the staged kernels take f32: convert into scratch that nothing writes before they have read it
+            const size_t n = (size_t)batch * rows * cols;
+            hipLaunchKernelGGL(k_u16_to_f32, dim3(1024), dim3(256), 0, st, d_src16, ctx->pp[1], n, in_scale);
+            d_src = ctx->pp[1];
         }
     }
     ctx->last_stream = st;
@@ -528,6 +537,14 @@ int dcmt_complete_f32_dev(dcmt_ctx* ctx, const float* d_src, float* d_dst, int r
     int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
     if (rc != DCMT_OK) return rc;
     return run_chain(ctx, d_src, nullptr, 0, 0, d_dst, rows, cols, batch, params, false, (hipStream_t)stream, false);
+}
+
+int dcmt_complete_u16_dev(dcmt_ctx* ctx, const uint16_t* d_src, float scale, float* d_dst, int rows, int cols, int batch,
+                          const dcmt_params* params, void* stream)
+{
+    int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
+    if (rc != DCMT_OK) return rc;
+    return run_chain(ctx, nullptr, nullptr, 0, 0, d_dst, rows, cols, batch, params, false, (hipStream_t)stream, false, d_src, scale);
 }
 
 int dcmt_complete_labeled_f32_dev(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_labels, float* d_dst,

@@ -128,6 +128,13 @@ struct RowRing {
     __device__ __forceinline__ float read(int s, int lane) const { return ring[((s >> 2) % SLOTS) * 256 + (s & 3) * 64 + lane]; }
 };
 
+// uint16 payload -> metres, for the paths that do not fuse the ingest (staged kernels)
+__global__ void k_u16_to_f32(const uint16_t* __restrict__ in, float* __restrict__ out, size_t n, float scale)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = __fmul_rn((float)in[i], scale);
+}
+
 // ---------------------------------------------------------------------------------
 // k_pre_s
 // ---------------------------------------------------------------------------------
@@ -147,11 +154,15 @@ struct PreS {
 
 // START4: the input is already X4 (the label-masked stage of the LC variant produced it): only H5 and H6
 // run; the row fed at step i is image row i - 6, so that all the ring slots below keep their meaning.
-template <int K0KIND, bool WIDE, bool START4 = false>
+// U16: the input is the KITTI uint16 depth PNG payload; metres = value * in_scale (the reference's ingest,
+// LO/main.cpp:75-82: imread(IMREAD_ANYDEPTH) + convertTo(CV_32F, 1./256)) is fused into the load.
+template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false>
 __global__ __launch_bounds__(256)
-void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, int cols, int strips,
-             int batch, int xcd_map, float max_depth, float thr)
+void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips,
+             int batch, int xcd_map, float max_depth, float thr, float in_scale)
 {
+    static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
+    const float* src = static_cast<const float*>(src_);
     using G = PreS<K0KIND, WIDE>;
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
     __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * 4 * 256 : 4];   // 4 waves x 4 slots x (4 rows x 64 columns)
@@ -166,6 +177,11 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
     const size_t fo = (size_t)f * rows * cols;
     const int gxc = min(max(gx, 0), cols - 1);       // loads are unconditional, from clamped addresses
     const float* sp = src + fo + gxc;
+    const uint16_t* sp16 = static_cast<const uint16_t*>(src_) + fo + gxc;
+    auto load_row = [&](int r) -> float {          // image row r (already clamped) of this lane's column
+        if constexpr (U16) return __fmul_rn((float)sp16[(size_t)r * cols], in_scale);
+        else return sp[(size_t)r * cols];
+    };
     float* op = x6 + fo + gxc;
     RowRing<4, ROFF> rr;
     if constexpr (WIDE) rr.init(s_ring + (strip & 3) * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
@@ -185,7 +201,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
         rr.issue(0); rr.issue(1); rr.issue(2);   // three 4-row blocks ahead
     } else {
 #pragma unroll
-        for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - ROFF, 0), rows - 1) * cols];
+        for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(q - ROFF, 0), rows - 1));
     }
 
     int ti = 0x7fffffff, bi = -1;                // first / last valid row of X5 in this lane's column
@@ -202,7 +218,7 @@ void k_pre_s(const float* __restrict__ src, float* __restrict__ x6, int rows, in
                 raw = rr.read(i, lane);
             } else {
                 raw = PF[p];
-                PF[(p + PFD) & 7] = sp[(size_t)min(max(i + PFD - ROFF, 0), rows - 1) * cols];
+                PF[(p + PFD) & 7] = load_row(min(max(i + PFD - ROFF, 0), rows - 1));
             }
             float e4;
             const int l = i - 6;

@@ -129,6 +129,13 @@ int dcmt_complete_f32(dcmt_ctx *ctx,
 int dcmt_complete_f32_dev(dcmt_ctx *ctx, const float *d_src, float *d_dst,
                           int rows, int cols, int batch, const dcmt_params *params, void *stream);
 
+/* The reference's ingest fused into the first kernel: d_src holds the KITTI uint16 depth PNG payload
+ * ([batch][rows][cols], device memory), metres = value * scale -- what src/DC_lidar_only/main.cpp:75-82
+ * does with imread(IMREAD_ANYDEPTH) + convertTo(CV_32F, 1./256) before calling img_completion.  Reads
+ * 2 instead of 4 bytes per pixel; otherwise identical to dcmt_complete_f32_dev on the converted frame. */
+int dcmt_complete_u16_dev(dcmt_ctx *ctx, const uint16_t *d_src, float scale, float *d_dst,
+                          int rows, int cols, int batch, const dcmt_params *params, void *stream);
+
 /* ---- interpolate_with_superpixels -------------------------------------------------- */
 
 /* As above with a label plane: int32 [rows][cols] ROW-MAJOR per frame (the reference keeps

@@ -310,3 +310,21 @@ def test_dispatch_toggles_give_identical_results(O):
     for env in ({"DCMT_FUSE_FP": "0"}, {"DCMT_WIDE": "0"}, {"DCMT_XCD_MAP": "0"}, {"DCMT_FUSE_FP": "0", "DCMT_WIDE": "0", "DCMT_XCD_MAP": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_uint16_ingest(O):
+    """The reference's ingest (main.cpp:75-82: uint16 PNG payload, convertTo(CV_32F, 1/256)) fused into the first
+    kernel: same bits as converting on the host and calling the f32 entry point -- streaming path (16 frames) and
+    staged path (2 frames)."""
+    import torch
+    for n in (16, 2):
+        u16 = np.round(synth.synth_batch(n, 352, 1216, 300) * 256.0).astype(np.uint16)
+        u16[0, 200, 300] = 65535                                  # 255.996 m: beyond max_depth
+        as_f32 = (u16.astype(np.float32) * np.float32(1.0 / 256.0)).astype(np.float32)
+        with api.Context(0, 352, 1216, n) as c:
+            d = torch.from_numpy(u16.view(np.int16)).cuda()       # torch has no uint16 arithmetic; the bytes are what matters
+            out = c.complete_u16_dev(d, 1.0 / 256.0)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+        for i in (0, n - 1):
+            assert_bit_equal(got[i], O.img_completion(as_f32[i]), f"u16 ingest n={n} frame {i}")
