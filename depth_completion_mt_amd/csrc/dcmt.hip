@@ -87,7 +87,6 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
 
 dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
 
-
 int k0_preset(uint32_t kb)
 {
     uint8_t k[25];
@@ -136,10 +135,12 @@ int fill_loop(dcmt_ctx* ctx, int batch, const dcmt_params* p, hipStream_t st, bo
     return rc;
 }
 
-// Fast path: k_pre_s -> k_fill_t (-> k_fill_loop_t ...) -> k_post_s.  Preconditions checked by the caller.
-// The batch is walked in chunks of ctx->chunk frames so that a chunk's intermediates (X6, X7:
-// 2 x 1.7 MB per frame) stay resident in the 256 MiB Infinity Cache between the three kernels.
+// Fast path.  Whole chain: k_pre_s -> k_fp_s, then three launches that return at once for every frame
+// k_fp_s finished (k_fill_s redo, k_fill_s loop applications, k_post_s only_if_holes).  stop_after probes:
+// k_pre_s -> k_fill_s (-> loop) -> k_post_s / copy.  Preconditions are checked by the caller.
+// ctx->chunk (env DCMT_CHUNK, default 0 = off) walks the batch in chunks; measured slower, kept as a knob.
 // d_x4 != nullptr: X4 is already there (LC fast path): k_pre_s only runs H5 + H6 on it.
+// d_src16 != nullptr: uint16 ingest fused into k_pre_s.
 int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst, int rows, int cols, int batch,
                     const dcmt_params* p, hipStream_t st, bool sync_loop, const float* d_x4 = nullptr,
                     const uint16_t* d_src16 = nullptr, float in_scale = 1.0f)

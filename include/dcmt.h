@@ -125,7 +125,8 @@ int dcmt_complete_f32(dcmt_ctx *ctx,
 
 /* DEVICE pointers, stream-ordered, asynchronous: the measured path.  d_src/d_dst are
  * contiguous [batch][rows][cols] f32 in device memory of ctx's GPU; `stream` is a
- * hipStream_t (NULL = the default stream).  Never synchronises, never allocates. */
+ * hipStream_t (NULL = the default stream).  Never synchronises; never allocates (the labeled variant
+ * grows its per-label bounding-box table the first time it sees a larger batch x n_labels). */
 int dcmt_complete_f32_dev(dcmt_ctx *ctx, const float *d_src, float *d_dst,
                           int rows, int cols, int batch, const dcmt_params *params, void *stream);
 
