@@ -64,6 +64,41 @@ def cpu_baseline(n_threads: int, cpu_work_s: float = 16.0):
             "single_thread_frames_per_s": 1.0 / t1}
 
 
+def dry_run(args, rank, world):
+    """The rank protocol of the real run -- barrier, K timed steps, barrier, max over ranks, one JSON line from
+    rank 0 -- over gloo with the GPU step replaced by a sleep.  Exercised by tests/test_sharding.py on CPU."""
+    import torch
+    import torch.distributed as dist
+    from depth_completion_mt_amd import sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    b, e = sharding.shard_range(B * world, rank, world)            # weak scaling: every rank owns B frames
+    assert e - b == B
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    if rank == 0:
+        print(json.dumps({"metric": "depth frames/sec at 1216x352 (KITTI); achieved HBM GB/s vs peak", "value": B * world * args.steps / elapsed,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "dry run (no GPU work)", "config": {"workload": "dry run", "frames_per_gpu_per_step": B}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +108,8 @@ def main():
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch1", action="store_true", help="also time batch=1 streamed launches (configs[1])")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank protocol (gloo, no GPU work, value is meaningless): tests only")
     args = ap.parse_args()
 
     import numpy as np
@@ -85,6 +122,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available() or L.lib().dcmt_device_count() < 1:
         raise SystemExit("bench.py needs a gfx950 GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -75,3 +75,22 @@ def test_two_rank_gloo_protocol(tmp_path):
     outs = [p.communicate(timeout=120) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0][0]
+
+
+def test_bench_rank_protocol_two_ranks_gloo():
+    """bench.py's own multi-rank plumbing (env parsing, barriers, max over ranks, ONE JSON line from rank 0)
+    launched exactly as the driver launches it, with --dry-run replacing the GPU step."""
+    import json
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 8
+    assert d["ms_per_step"] >= 4.0          # the slower rank (2 x 2 ms per step) sets the time
+    # a mismatch between --gpus and the launched world size is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
