@@ -14,9 +14,11 @@ LIB_PATH = os.path.join(_CSRC, "libdcmt_hip.so")
 
 OK, E_INVALID, E_UNSUPPORTED, E_NOMEM, E_HIP, E_NOT_CONVERGED, E_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 BLUR_NONE, BLUR_GAUSSIAN, BLUR_BILATERAL = 0, 1, 2
+STAGE_NORMALIZE = 1
 STAGE_INVERT, STAGE_DILATE_K, STAGE_CLOSE5, STAGE_FILL7, STAGE_EXTEND = 2, 3, 4, 5, 6
 FLAG_FORCE_STAGED = 1
 FLAG_FORCE_FUSED = 2
+FLAG_NORMALIZE = 4
 STAGE_FILL31, STAGE_FILLLOOP, STAGE_MEDIAN5, STAGE_BLUR, STAGE_FINAL = 7, 8, 9, 10, 11
 
 # every symbol include/dcmt.h declares (tests check the library exports exactly these)
@@ -41,6 +43,8 @@ class Params(ctypes.Structure):
         ("stop_after", ctypes.c_int32),
         ("verbose", ctypes.c_int32),
         ("flags", ctypes.c_int32),
+        ("norm_lo", ctypes.c_float),
+        ("norm_hi", ctypes.c_float),
     ]
 
 

@@ -27,7 +27,10 @@ class DcmtError(RuntimeError):
 
 def make_params(k0="as_compiled", blur_type: str = "gaussian", stop_after: int = L.STAGE_FINAL,
                 max_fill_iters: int = 64, spec_fill_iters: int = 1, verbose: bool = False,
-                max_depth: float = 100.0, valid_thresh: float = 0.1, force_staged: bool = False, force_fused: bool = False) -> L.Params:
+                max_depth: float = 100.0, valid_thresh: float = 0.1, force_staged: bool = False, force_fused: bool = False,
+                normalize=None) -> L.Params:
+    """normalize=(lo, hi): min-max normalise every frame first, as cv::normalize(src, dst, lo, hi, NORM_MINMAX)
+    in front of the path does in the stereo-lidar executables (SL/main_sl.cpp:370, :523)."""
     p = L.Params()
     L.lib().dcmt_default_params(ctypes.byref(p))
     if isinstance(k0, str):
@@ -48,6 +51,9 @@ def make_params(k0="as_compiled", blur_type: str = "gaussian", stop_after: int =
     p.max_depth = float(max_depth)
     p.valid_thresh = float(valid_thresh)
     p.flags = (L.FLAG_FORCE_STAGED if force_staged else 0) | (L.FLAG_FORCE_FUSED if force_fused else 0)
+    if normalize is not None:
+        p.flags |= L.FLAG_NORMALIZE
+        p.norm_lo, p.norm_hi = float(normalize[0]), float(normalize[1])
     return p
 
 

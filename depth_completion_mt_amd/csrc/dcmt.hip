@@ -28,6 +28,8 @@ struct dcmt_ctx {
     float* pp[2] = {nullptr, nullptr};// ping-pong of the large-fill applications
     int* colstat = nullptr;           // [max_batch][2][cols]
     int* counters = nullptr;          // [max_batch][kCntStride]
+    uint32_t* norm_stats = nullptr;   // [max_batch][2]  N1: order-preserving keys of each frame's max and (inverted) min
+    float* norm_coef = nullptr;       // [max_batch][2]  N1: dst = src * a + b
     // host-entry staging (allocated on first use)
     float* d_in = nullptr;
     float* d_out = nullptr;
@@ -71,6 +73,14 @@ uint32_t k0_bits(const uint8_t k0[25])
     return b;
 }
 
+// the library is built with -ffinite-math-only: test the exponent bits, not the value
+bool finite_bits(float v)
+{
+    uint32_t b;
+    std::memcpy(&b, &v, sizeof b);
+    return (b & 0x7f800000u) != 0x7f800000u;
+}
+
 int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, int cols, int batch, const dcmt_params* p)
 {
     if (!ctx || !a || !b || !p) return DCMT_E_INVALID;
@@ -80,7 +90,9 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
     if (p->blur != DCMT_BLUR_NONE && p->blur != DCMT_BLUR_GAUSSIAN) return DCMT_E_INVALID;
     if (p->max_fill_iters < 1 || p->max_fill_iters > kMaxIters) return DCMT_E_INVALID;
     if (p->spec_fill_iters < 0 || p->spec_fill_iters > kMaxIters) return DCMT_E_INVALID;
-    if (p->stop_after < DCMT_STAGE_INVERT || p->stop_after > DCMT_STAGE_FINAL) return DCMT_E_INVALID;
+    const bool norm = (p->flags & DCMT_FLAG_NORMALIZE) != 0;
+    if (p->stop_after < (norm ? DCMT_STAGE_NORMALIZE : DCMT_STAGE_INVERT) || p->stop_after > DCMT_STAGE_FINAL) return DCMT_E_INVALID;
+    if (norm && !(finite_bits(p->norm_lo) && finite_bits(p->norm_hi))) return DCMT_E_INVALID;
     if (k0_bits(p->k0) == 0) return DCMT_E_INVALID;
     return DCMT_OK;
 }
@@ -143,7 +155,7 @@ int fill_loop(dcmt_ctx* ctx, int batch, const dcmt_params* p, hipStream_t st, bo
 // d_src16 != nullptr: uint16 ingest fused into k_pre_s.
 int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst, int rows, int cols, int batch,
                     const dcmt_params* p, hipStream_t st, bool sync_loop, const float* d_x4 = nullptr,
-                    const uint16_t* d_src16 = nullptr, float in_scale = 1.0f)
+                    const uint16_t* d_src16 = nullptr, float in_scale = 1.0f, const float* coef = nullptr)
 {
     const int stop = p->stop_after;
     ctx->last_stream = st;
@@ -164,6 +176,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         float* pp0 = ctx->pp[0] + f0 * fe;
         float* pp1 = ctx->pp[1] + f0 * fe;
         int* cnt = ctx->counters + (size_t)f0 * kCntStride;
+        const float* cf = coef ? coef + 2 * (size_t)f0 : nullptr;
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
             // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
@@ -171,11 +184,13 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr;
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
                 if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
-                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f); \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr); \
                 else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src16, o6, \
-                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale); \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr); \
+                else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf); \
                 else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
-                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f); }
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr); }
             if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
             else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
 #undef DCMT_PRE
@@ -261,6 +276,25 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     const uint32_t kb = k0_bits(p->k0);
     const int stop = p->stop_after;
     const int blur = force_gaussian ? (int)DCMT_BLUR_GAUSSIAN : p->blur;
+    const float* coef = nullptr;
+    if (p->flags & DCMT_FLAG_NORMALIZE) {
+        // N1: one read-only pass for the per-frame extrema, then (a, b) per frame; the first kernel of whichever
+        // path runs below applies them while it loads
+        if (d_src16) return DCMT_E_UNSUPPORTED;
+        const size_t fe = (size_t)rows * cols;
+        DCMT_HIP(ctx, hipMemsetAsync(ctx->norm_stats, 0, sizeof(uint32_t) * 2 * (size_t)batch, st));
+        hipLaunchKernelGGL(k_minmax, dim3(kMinmaxUnits * batch), dim3(256), 0, st, d_src, ctx->norm_stats, fe, batch,
+                           (ctx->xcd_map && batch % 8 == 0) ? 1 : 0);
+        hipLaunchKernelGGL(k_norm_coef, dim3((batch + 63) / 64), dim3(64), 0, st, ctx->norm_stats, ctx->norm_coef, batch, p->norm_lo, p->norm_hi);
+        DCMT_HIP(ctx, hipGetLastError());
+        coef = ctx->norm_coef;
+        if (stop == DCMT_STAGE_NORMALIZE) {
+            hipLaunchKernelGGL(k_norm_write, dim3(2048), dim3(256), 0, st, d_src, d_dst, coef, fe, batch);
+            DCMT_HIP(ctx, hipGetLastError());
+            ctx->last_stream = st; ctx->last_batch = batch; ctx->last_apps_launched = 0; ctx->last_has_loop = 0;
+            return DCMT_OK;
+        }
+    }
     {
         const int kind = k0_preset(kb);
         const bool labeled = d_labels && use_superpixel;
@@ -285,17 +319,16 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             const size_t table = sizeof(int) * 4 * (size_t)n_labels;
             if (table <= 48 * 1024)
                 hipLaunchKernelGGL(k_label_bbox<true>, bg, dim3(256), table, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
-                                   rows, cols, p->max_depth, p->valid_thresh);
+                                   rows, cols, p->max_depth, p->valid_thresh, coef);
             else
                 hipLaunchKernelGGL(k_label_bbox<false>, bg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
-                                   rows, cols, p->max_depth, p->valid_thresh);
+                                   rows, cols, p->max_depth, p->valid_thresh, coef);
             const dim3 lg((n_labels + 3) / 4, batch);
-            if (kind == K0_AS_COMPILED)
-                hipLaunchKernelGGL((k_label_stage_s<K0_AS_COMPILED>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max,
-                                   x4, rows, cols, p->max_depth, p->valid_thresh);
-            else
-                hipLaunchKernelGGL((k_label_stage_s<K0_DIAMOND>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max,
-                                   x4, rows, cols, p->max_depth, p->valid_thresh);
+#define DCMT_LSTAGE(KIND, NORM) hipLaunchKernelGGL((k_label_stage_s<KIND, NORM>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, \
+                                                   ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef)
+            if (kind == K0_AS_COMPILED) { if (coef) DCMT_LSTAGE(K0_AS_COMPILED, true); else DCMT_LSTAGE(K0_AS_COMPILED, false); }
+            else { if (coef) DCMT_LSTAGE(K0_DIAMOND, true); else DCMT_LSTAGE(K0_DIAMOND, false); }
+#undef DCMT_LSTAGE
             DCMT_HIP(ctx, hipGetLastError());
             if (stop == DCMT_STAGE_CLOSE5) {
                 ctx->last_stream = st; ctx->last_batch = batch; ctx->last_apps_launched = 0; ctx->last_has_loop = 0;
@@ -309,7 +342,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             stop >= DCMT_STAGE_EXTEND) {
             dcmt_params q = *p;
             q.blur = blur;
-            return run_chain_fused(ctx, kind, d_src, d_dst, rows, cols, batch, &q, st, sync_loop, nullptr, d_src16, in_scale);
+            return run_chain_fused(ctx, kind, d_src, d_dst, rows, cols, batch, &q, st, sync_loop, nullptr, d_src16, in_scale, coef);
         }
         if (d_src16) {   // the staged kernels take f32: convert into scratch that nothing writes before they have read it
             const size_t n = (size_t)batch * rows * cols;
@@ -332,11 +365,11 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     if (d_labels && use_superpixel) {
         hipLaunchKernelGGL((k_pre_labeled_v1<TH, TW>), grid, block, 0, st, d_src, d_labels, n_labels,
                            stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, d_dst, rows, cols,
-                           p->max_depth, p->valid_thresh, kb, dump);
+                           p->max_depth, p->valid_thresh, kb, dump, coef);
     } else {
         hipLaunchKernelGGL((k_pre_v1<TH, TW>), grid, block, 0, st, d_src,
                            stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, d_dst, rows, cols,
-                           p->max_depth, p->valid_thresh, kb, dump);
+                           p->max_depth, p->valid_thresh, kb, dump, coef);
     }
     DCMT_HIP(ctx, hipGetLastError());
     if (stop <= DCMT_STAGE_FILL7) return DCMT_OK;
@@ -467,6 +500,8 @@ void dcmt_default_params(dcmt_params* p)
     p->spec_fill_iters = 1;
     p->stop_after = DCMT_STAGE_FINAL;
     p->verbose = 0;
+    p->norm_lo = 0.0f;
+    p->norm_hi = 100.0f;      // SL/main_sl.cpp:370 (the labeled call at :523 uses 80)
 }
 
 int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx** out)
@@ -498,6 +533,8 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->h_counters, sizeof(int) * (size_t)kCntStride * max_batch, hipHostMallocDefault) != hipSuccess)
         return fail(DCMT_E_NOMEM);
     *out = ctx;
@@ -511,6 +548,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
     (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters);
+    (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
     (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);

@@ -156,12 +156,15 @@ struct PreS {
 // run; the row fed at step i is image row i - 6, so that all the ring slots below keep their meaning.
 // U16: the input is the KITTI uint16 depth PNG payload; metres = value * in_scale (the reference's ingest,
 // LO/main.cpp:75-82: imread(IMREAD_ANYDEPTH) + convertTo(CV_32F, 1./256)) is fused into the load.
-template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false>
+// NORM: N1's per-frame min-max normalisation (coef[2f], coef[2f+1] from k_norm_coef) applied to every
+// raw value before H2 -- cv::normalize in front of the path, SL/main_sl.cpp:370 / :523.
+template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false, bool NORM = false>
 __global__ __launch_bounds__(256)
 void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips,
-             int batch, int xcd_map, float max_depth, float thr, float in_scale)
+             int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef)
 {
     static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
+    static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
     const float* src = static_cast<const float*>(src_);
     using G = PreS<K0KIND, WIDE>;
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
@@ -176,6 +179,8 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     const bool outlane = incol && lane >= G::HL && lane < G::HL + G::VW;
     const size_t fo = (size_t)f * rows * cols;
     const int gxc = min(max(gx, 0), cols - 1);       // loads are unconditional, from clamped addresses
+    float na = 1.0f, nb = 0.0f;
+    if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
     const float* sp = src + fo + gxc;
     const uint16_t* sp16 = static_cast<const uint16_t*>(src_) + fo + gxc;
     auto load_row = [&](int r) -> float {          // image row r (already clamped) of this lane's column
@@ -225,6 +230,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             if constexpr (START4) {
                 e4 = raw;                                               // X4 row l
             } else {
+            if constexpr (NORM) raw = norm_apply(raw, na, nb);
             const float x2 = (incol && i < rows) ? invert_valid(raw, max_depth, thr) : NEG;
             // ---- H3 (LO :71-80), row j = i - 2
             const int j = i - 2;
@@ -308,7 +314,7 @@ template <bool LDS_TABLE>
 __global__ __launch_bounds__(256)
 void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
                   int* __restrict__ bb_min, int* __restrict__ bb_max, float* __restrict__ x4,
-                  int rows, int cols, float max_depth, float thr)
+                  int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
 {
     extern __shared__ __attribute__((aligned(16))) int s_bb[];     // LDS_TABLE: [n_labels][4] = ymin, xmin, ymax, xmax
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -339,7 +345,11 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
             if (lv && l != left) { atomicMin(&mn[2 * l], gy); atomicMax(&mx[2 * l], gy); atomicMin(&mn[2 * l + 1], gx); }
             if (lv && l != right) atomicMax(&mx[2 * l + 1], gx);
         }
-        if (in && !lv) x4[fo + (size_t)gy * cols + gx] = invert_valid(src[fo + (size_t)gy * cols + gx], max_depth, thr);
+        if (in && !lv) {
+            float v = src[fo + (size_t)gy * cols + gx];
+            if (coef) v = norm_apply(v, coef[2 * f], coef[2 * f + 1]);    // N1 normalisation, if any
+            x4[fo + (size_t)gy * cols + gx] = invert_valid(v, max_depth, thr);
+        }
     }
     if constexpr (LDS_TABLE) {
         __syncthreads();
@@ -352,11 +362,11 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
     }
 }
 
-template <int K0KIND>
+template <int K0KIND, bool NORM>
 __global__ __launch_bounds__(256)
 void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
                      const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
-                     int rows, int cols, float max_depth, float thr)
+                     int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
 {
     constexpr int H = 6, VW = 64 - 2 * H;          // reach of H3 + H4 (diamond: 6 / 6), 52 output columns per chunk
     constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
@@ -368,6 +378,8 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
     const int y1 = bb_max[((size_t)f * n_labels + L) * 2], x1 = bb_max[((size_t)f * n_labels + L) * 2 + 1];
     if (y1 < 0) return;                            // the label owns no pixel
     const size_t fo = (size_t)f * rows * cols;
+    float na = 1.0f, nb = 0.0f;                    // N1 normalisation
+    if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
     for (int cx = x0; cx <= x1; cx += VW) {
         const int gx = cx - H + lane;
         const bool incol = gx >= 0 && gx < cols;
@@ -402,7 +414,7 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
                 // masked copy (LC :94-95): the label's pixels keep their H2 value, other image pixels are 0;
                 // outside the image the dilate border value
                 const bool inimg = incol && (unsigned)i < (unsigned)rows;
-                const float x2 = inimg ? (lab == L ? invert_valid(raw, max_depth, thr) : 0.0f) : NEG;
+                const float x2 = inimg ? (lab == L ? invert_valid(NORM ? norm_apply(raw, na, nb) : raw, max_depth, thr) : 0.0f) : NEG;
                 const int j = i - 2;
                 float y3;
                 if constexpr (K0KIND == K0_AS_COMPILED) {

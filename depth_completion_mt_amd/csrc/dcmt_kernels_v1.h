@@ -56,6 +56,82 @@ __device__ __forceinline__ float invert_valid(float v, float max_depth, float th
 }
 
 // ---------------------------------------------------------------------------------
+// N1: per-frame min-max normalisation in front of the cascade -- what the stereo-lidar callers do with
+// cv::normalize(projected, normalized, 0, 80 | 100, NORM_MINMAX) before they call the path
+// (SL/main_sl.cpp:370, :523).  OpenCV semantics restated: smin/smax = the frame's extrema;
+//   scale = (dmax - dmin) * (smax - smin > DBL_EPSILON ? 1 / (smax - smin) : 0)   in double,
+//   for a CV_32F destination  scale = (float)scale,  shift = (float)dmin - (float)(smin * scale),
+//   dst = src * (float)scale + (float)shift        (convertTo, f32 arithmetic, one rounding per op).
+// With empty pixels (0) in the frame smin = 0, so shift = dmin and for dmin = 0 the result is the
+// single rounding of src * scale: bit-exact whatever the host library fuses.
+// k_minmax leaves per frame {max of key(x), max of ~key(x)} (key = order-preserving u32 image of
+// the float), k_norm_coef turns them into the f32 pair (a, b) the first kernel of the chain applies.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_key(float v)
+{
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unkey(uint32_t k)
+{
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float norm_apply(float v, float a, float b) { return __fadd_rn(__fmul_rn(v, a), b); }
+
+constexpr int kMinmaxUnits = 8;              // workgroups per frame
+
+__global__ __launch_bounds__(256)
+void k_minmax(const float* __restrict__ src, uint32_t* __restrict__ stats, size_t frame_elems, int batch, int xcd_map)
+{
+    int f, u;
+    if (xcd_map) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; f = (slot / kMinmaxUnits) * 8 + xcd; u = slot % kMinmaxUnits; }
+    else { f = blockIdx.x / kMinmaxUnits; u = blockIdx.x - f * kMinmaxUnits; }
+    (void)batch;
+    const float* s = src + (size_t)f * frame_elems;
+    const size_t per = (frame_elems + kMinmaxUnits - 1) / kMinmaxUnits;
+    const size_t b0 = (size_t)u * per, b1 = b0 + per < frame_elems ? b0 + per : frame_elems;
+    float lo0 = FLT_MAX, lo1 = FLT_MAX, lo2 = FLT_MAX, lo3 = FLT_MAX, hi0 = -FLT_MAX, hi1 = -FLT_MAX, hi2 = -FLT_MAX, hi3 = -FLT_MAX;
+    size_t i = b0 + threadIdx.x;
+    for (; i + 768 < b1; i += 1024) {        // four independent coalesced dword loads in flight per thread
+        const float v0 = s[i], v1 = s[i + 256], v2 = s[i + 512], v3 = s[i + 768];
+        lo0 = fmin2(lo0, v0); hi0 = fmax2(hi0, v0); lo1 = fmin2(lo1, v1); hi1 = fmax2(hi1, v1);
+        lo2 = fmin2(lo2, v2); hi2 = fmax2(hi2, v2); lo3 = fmin2(lo3, v3); hi3 = fmax2(hi3, v3);
+    }
+    for (; i < b1; i += 256) { const float v = s[i]; lo0 = fmin2(lo0, v); hi0 = fmax2(hi0, v); }
+    float lo = fmin2(fmin2(lo0, lo1), fmin2(lo2, lo3)), hi = fmax2(fmax2(hi0, hi1), fmax2(hi2, hi3));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin2(lo, __shfl_xor(lo, o, 64)); hi = fmax2(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0 && b0 < b1) {
+        atomicMax(&stats[2 * f], f32_key(hi));
+        atomicMax(&stats[2 * f + 1], ~f32_key(lo));
+    }
+}
+
+__global__ void k_norm_coef(const uint32_t* __restrict__ stats, float* __restrict__ coef, int batch, float lo, float hi)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= batch) return;
+    const double smax = (double)f32_unkey(stats[2 * f]), smin = (double)f32_unkey(~stats[2 * f + 1]);
+    const double dmin = lo < hi ? (double)lo : (double)hi, dmax = lo < hi ? (double)hi : (double)lo;
+    double scale = (dmax - dmin) * (smax - smin > 2.220446049250313e-16 ? 1.0 / (smax - smin) : 0.0);
+    scale = (double)(float)scale;
+    const double shift = (double)(float)dmin - (double)(float)(smin * scale);
+    coef[2 * f] = (float)scale;
+    coef[2 * f + 1] = (float)shift;
+}
+
+// the normalised frames themselves (stop_after = DCMT_STAGE_NORMALIZE)
+__global__ __launch_bounds__(256)
+void k_norm_write(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ coef, size_t frame_elems, int batch)
+{
+    const size_t n = frame_elems * (size_t)batch;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / frame_elems;
+        dst[i] = norm_apply(src[i], coef[2 * f], coef[2 * f + 1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // init: column statistics and counters for one call
 // ---------------------------------------------------------------------------------
 __global__ void k_init(int* __restrict__ colstat, int* __restrict__ counters, int cols, int batch)
@@ -139,7 +215,7 @@ template <int TH, int TW>
 __global__ __launch_bounds__(kThreads)
 void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __restrict__ colstat,
               float* __restrict__ dump, int rows, int cols, float max_depth, float thr,
-              uint32_t k0bits, int dump_stage)
+              uint32_t k0bits, int dump_stage, const float* __restrict__ coef)
 {
     using G = PreGeom<TH, TW>;
     constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
@@ -151,12 +227,17 @@ void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __rest
     const int ty0 = blockIdx.y * TH - R, tx0 = blockIdx.x * TW - R;
     const size_t fo = (size_t)f * rows * cols;
     const float* s = src + fo;
+    const float na = coef ? coef[2 * f] : 1.0f, nb = coef ? coef[2 * f + 1] : 0.0f;   // N1 normalisation, if any
 
     // H2 (LO :55-67) on load; outside the image: border value of the dilate that follows
     for_rect(0, RH, 0, RW, [&](int y, int x) {
         const int gy = ty0 + y, gx = tx0 + x;
         float v = -FLT_MAX;
-        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = invert_valid(s[(size_t)gy * cols + gx], max_depth, thr);
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) {
+            v = s[(size_t)gy * cols + gx];
+            if (coef) v = norm_apply(v, na, nb);
+            v = invert_valid(v, max_depth, thr);
+        }
         A[y * P + x] = v;
     });
     __syncthreads();
@@ -220,7 +301,8 @@ template <int TH, int TW>
 __global__ __launch_bounds__(kThreads)
 void k_pre_labeled_v1(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
                       float* __restrict__ x5, int* __restrict__ colstat, float* __restrict__ dump,
-                      int rows, int cols, float max_depth, float thr, uint32_t k0bits, int dump_stage)
+                      int rows, int cols, float max_depth, float thr, uint32_t k0bits, int dump_stage,
+                      const float* __restrict__ coef)
 {
     using G = PreGeom<TH, TW>;
     constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
@@ -238,13 +320,16 @@ void k_pre_labeled_v1(const float* __restrict__ src, const int32_t* __restrict__
     const size_t fo = (size_t)f * rows * cols;
     const float* s = src + fo;
     const int32_t* lab = labels + fo;
+    const float na = coef ? coef[2 * f] : 1.0f, nb = coef ? coef[2 * f + 1] : 0.0f;   // N1 normalisation, if any
 
     for_rect(0, RH, 0, RW, [&](int y, int x) {
         const int gy = ty0 + y, gx = tx0 + x;
         float v = -FLT_MAX;
         int l = -2;
         if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) {
-            v = invert_valid(s[(size_t)gy * cols + gx], max_depth, thr);
+            v = s[(size_t)gy * cols + gx];
+            if (coef) v = norm_apply(v, na, nb);
+            v = invert_valid(v, max_depth, thr);
             l = lab[(size_t)gy * cols + gx];
             if (l < 0 || l >= n_labels) l = -1;     // never matched by the loop `c in [0,n)` (LC :78)
         }

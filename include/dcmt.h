@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCMT_VERSION 100 /* 0.1.0 */
+#define DCMT_VERSION 110 /* 0.1.1: dcmt_params grew norm_lo / norm_hi (DCMT_FLAG_NORMALIZE) */
 
 typedef struct dcmt_ctx dcmt_ctx;
 
@@ -50,6 +50,8 @@ typedef enum {
 
 /* Stages of the cascade, for `stop_after` (parity probes; 11 = the whole chain). */
 typedef enum {
+    DCMT_STAGE_NORMALIZE = 1, /* only with DCMT_FLAG_NORMALIZE: the min-max normalised frames themselves
+                                 (cv::normalize in front of the path, DC_stereo_lidar/main_sl.cpp:370, :523) */
     DCMT_STAGE_INVERT   = 2,  /* img_completion.cpp:55-67   */
     DCMT_STAGE_DILATE_K = 3,  /* :71-80   first dilate, element k0 */
     DCMT_STAGE_CLOSE5   = 4,  /* :84-85   5x5 close (LC: the label-masked stage, img_completion_lc.cpp:78-102) */
@@ -80,6 +82,8 @@ typedef struct {
     int32_t stop_after;      /* dcmt_stage; DCMT_STAGE_FINAL for the whole chain */
     int32_t verbose;         /* 1: print what the reference prints (dims, hole counts) to stdout (host entry points) */
     int32_t flags;           /* DCMT_FLAG_* */
+    float   norm_lo;         /* DCMT_FLAG_NORMALIZE: the two range arguments of cv::normalize (alpha, beta); */
+    float   norm_hi;         /* the stereo-lidar callers pass (0, 100) and (0, 80).  Defaults 0, 100. */
 } dcmt_params;
 
 /* Use the general staged kernels even where the fused fast path applies (A/B tests, debugging).
@@ -89,6 +93,15 @@ typedef struct {
  * batches of fewer than 12 frames take the staged tile kernels, whose many small workgroups have the
  * lower latency for a single frame).  Both paths produce identical bits. */
 #define DCMT_FLAG_FORCE_FUSED 2
+
+/* The caller-side pre-step of the stereo-lidar executables fused in front of the cascade: every frame is first
+ * min-max normalised, exactly as `cv::normalize(src, dst, norm_lo, norm_hi, cv::NORM_MINMAX)` does for a
+ * CV_32F destination (DC_stereo_lidar/main_sl.cpp:370 before img_completion, :523 before
+ * interpolate_with_superpixels): one extra read-only pass finds each frame's extrema, the first kernel of
+ * the chain applies dst = src * a + b (f32, unfused) while it loads.  f32 entry points only
+ * (dcmt_complete_u16_dev returns DCMT_E_UNSUPPORTED: the reference never combines the two ingests).
+ * A frame whose values are all equal normalises to min(norm_lo, norm_hi) everywhere, as in OpenCV. */
+#define DCMT_FLAG_NORMALIZE 4
 
 /* ---- lifetime --------------------------------------------------------------------- */
 

@@ -84,7 +84,7 @@ inline void raise(int st, const char* what)
 inline void interpolate_with_labels(const std::vector<std::vector<int> >& clusters, int n_labels,
                                     const cv::Mat& sparse_r_img, cv::Mat& dense_r_img,
                                     const std::string& /*blur_type: unused by the reference, img_completion_lc.cpp:183*/,
-                                    int use_superpixel)
+                                    int use_superpixel, const double* normalize_range = nullptr /* {alpha, beta}: see below */)
 {
     check_input(sparse_r_img);
     const int rows = sparse_r_img.rows, cols = sparse_r_img.cols;
@@ -100,10 +100,35 @@ inline void interpolate_with_labels(const std::vector<std::vector<int> >& cluste
     out.create(rows, cols, CV_32FC1);
     dcmt_params p;
     dcmt_default_params(&p);
+    if (normalize_range) { p.flags |= DCMT_FLAG_NORMALIZE; p.norm_lo = (float)normalize_range[0]; p.norm_hi = (float)normalize_range[1]; }
     const int st = dcmt_complete_labeled_f32(thread_ctx().get(rows, cols), sparse_r_img.ptr<float>(), sparse_r_img.step[0], 0,
                                              lab.data(), sizeof(int32_t) * (size_t)cols, 0, n_labels, out.ptr<float>(),
                                              out.step[0], 0, rows, cols, 1, &p, use_superpixel);
     raise(st, "interpolate_with_superpixels");
+    dense_r_img = out;
+}
+
+// The stereo-lidar callers' two lines in one call (DC_stereo_lidar/main_sl.cpp:370 + :386):
+//     cv::normalize(projected, normalized, alpha, beta, cv::NORM_MINMAX);  img_completion(normalized, dense, extr, blur);
+// the min-max pass runs on the GPU in front of the cascade (DCMT_FLAG_NORMALIZE) and the normalised image is never
+// materialised.  For the labeled variant (:523 + :540) pass normalize_range to interpolate_with_labels.
+inline void img_completion_normalized(const cv::Mat& projected, cv::Mat& dense_r_img, double alpha, double beta,
+                                      const bool& /*extr*/, const std::string& blur_type)
+{
+    check_input(projected);
+    const int rows = projected.rows, cols = projected.cols;
+    std::cout << "NUMERO ROWS, COLS: " << rows << " " << cols << std::endl;   // img_completion.cpp:29
+    cv::Mat out;
+    out.create(rows, cols, CV_32FC1);
+    dcmt_params p;
+    dcmt_default_params(&p);
+    p.blur = blur_from_string(blur_type);
+    p.flags |= DCMT_FLAG_NORMALIZE;
+    p.norm_lo = (float)alpha;
+    p.norm_hi = (float)beta;
+    const int st = dcmt_complete_f32(thread_ctx().get(rows, cols), projected.ptr<float>(), projected.step[0], 0,
+                                     out.ptr<float>(), out.step[0], 0, rows, cols, 1, &p);
+    raise(st, "img_completion_normalized");
     dense_r_img = out;
 }
 

@@ -92,6 +92,10 @@ void dcmt_oracle_median5_simple(const float *src, float *dst, int rows, int cols
 void dcmt_oracle_gaussian5(const float *src, float *dst, int rows, int cols);
 void dcmt_oracle_extend_columns(float *x, int rows, int cols);
 
+/* N1: cv::normalize(src, dst, a, b, NORM_MINMAX) for CV_32F, the pre-step of the stereo-lidar callers
+ * (DC_stereo_lidar/main_sl.cpp:370, :523). */
+void dcmt_oracle_normalize_minmax(const float *src, float *dst, int rows, int cols, float a, float b);
+
 /* Deterministic KITTI-like synthetic sparse frame. */
 void dcmt_oracle_synth_frame(float *dst, int rows, int cols, uint64_t seed);
 

@@ -104,6 +104,17 @@ def extend_columns(x):
     return x
 
 
+def normalize_minmax(x, lo, hi):
+    """cv::normalize(x, dst, lo, hi, NORM_MINMAX) for CV_32F (SL/main_sl.cpp:370, :523): see dcmt_oracle.c."""
+    x = np.asarray(x, dtype=F32)
+    smin, smax = np.float64(x.min()), np.float64(x.max())
+    dmin, dmax = np.float64(min(lo, hi)), np.float64(max(lo, hi))
+    scale = (dmax - dmin) * (1.0 / (smax - smin) if smax - smin > np.finfo(np.float64).eps else 0.0)
+    scale = np.float64(F32(scale))
+    shift = np.float64(F32(dmin)) - np.float64(F32(smin * scale))
+    return (x * F32(scale)).astype(F32) + F32(shift)
+
+
 def median5(x):
     """cv::medianBlur(x,x,5) on f32: exact median, BORDER_REPLICATE (LO :170)."""
     R, C = x.shape

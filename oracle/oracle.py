@@ -78,6 +78,8 @@ def lib(native: bool = False) -> ctypes.CDLL:
             getattr(L, n).restype = None
         L.dcmt_oracle_extend_columns.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         L.dcmt_oracle_extend_columns.restype = None
+        L.dcmt_oracle_normalize_minmax.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+        L.dcmt_oracle_normalize_minmax.restype = None
         L.dcmt_oracle_synth_frame.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
         L.dcmt_oracle_synth_frame.restype = None
         _libs[native] = L
@@ -196,6 +198,11 @@ def extend_columns(a):
     x = _c32(a).copy()
     lib().dcmt_oracle_extend_columns(_fp(x), x.shape[0], x.shape[1])
     return x
+
+
+def normalize_minmax(a, lo: float, hi: float) -> np.ndarray:
+    """cv::normalize(a, dst, lo, hi, NORM_MINMAX), f32 (SL/main_sl.cpp:370, :523)."""
+    return _unary("dcmt_oracle_normalize_minmax", a, ctypes.c_float(lo), ctypes.c_float(hi))
 
 
 def synth_frame(rows: int, cols: int, seed: int) -> np.ndarray:

@@ -93,6 +93,21 @@ def main():
     out["lc40x56_out"] = N.interpolate_with_superpixels(x, lab, nl)
     out["lc40x56_out_nosp"] = N.interpolate_with_superpixels(x, lab, nl, use_superpixel=0)
     meta["lc40x56_n_labels"] = nl
+    # N1: min-max normalisation in front of the path (SL/main_sl.cpp:370 with (0,100), :523 with (0,80))
+    x = synth.synth_frame(48, 64, 31)
+    out["norm48x64_in"] = x
+    out["norm48x64_n100"] = N.normalize_minmax(x, 0, 100)
+    out["norm48x64_out100"] = N.img_completion(out["norm48x64_n100"])
+    out["norm48x64_stage2_100"] = N.img_completion(out["norm48x64_n100"], stop_after=2)
+    out["norm48x64_out80_diamond"] = N.img_completion(N.normalize_minmax(x, 0, 80), k0=N.K0_DIAMOND)
+    x = synth.synth_frame(40, 56, 21)
+    out["norm_lc40x56_out80"] = N.interpolate_with_superpixels(N.normalize_minmax(x, 0, 80), lab, nl)
+    # no empty pixel, negative values: smin != 0, so the shift term is live (tolerance class, see dcmt_oracle.c)
+    x = synth.synth_frame(40, 56, 13); x[x == 0] = 7.5; x[3, 4] = -2.25
+    out["norm_dense40x56_in"] = x
+    out["norm_dense40x56_n80"] = N.normalize_minmax(x, 0, 80)
+    out["norm_dense40x56_out80"] = N.img_completion(out["norm_dense40x56_n80"])
+    out["norm_flat_n"] = N.normalize_minmax(np.full((8, 8), 2.0, np.float32), 5, 80)     # constant frame -> dmin everywhere
     np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **out)
 
     # full-size frames: checksums only (inputs come from the generator)

@@ -2,7 +2,7 @@
 // (src/DC_lidar_only/main.cpp:93: img_completion(sparse, dense, false, "gaussian")) and as
 // main_lc.cpp:220 calls interpolate_with_superpixels.  Reads raw f32/int32 files written by the
 // pytest driver, writes raw f32 results; the driver compares them with the oracle.
-//   shim_test <rows> <cols> <in.f32> <out.f32> [labels.i32 n_labels out_lc.f32]
+//   shim_test <rows> <cols> <in.f32> <out.f32> [labels.i32 n_labels out_lc.f32 [out_norm100.f32 out_lc_norm80.f32]]
 #include "img_completion.h"
 
 #include <cstdio>
@@ -59,6 +59,18 @@ int main(int argc, char** argv)
         dcmt_shim::interpolate_with_labels(clusters, n_labels, sparse, dense_sp, "gaussian", 1);
         for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], dense_sp.ptr<float>(r), (size_t)cols * 4);
         if (!write_all(argv[7], out.data(), out.size() * 4)) return 9;
+        if (argc >= 10) {
+            // the stereo-lidar callers: cv::normalize(..., 0, 100) + img_completion (main_sl.cpp:370, :386) and
+            // cv::normalize(..., 0, 80) + interpolate_with_superpixels (:523, :540), each as one fused call
+            cv::Mat dense_n;
+            dcmt_shim::img_completion_normalized(sparse, dense_n, 0, 100, false, "gaussian");
+            for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], dense_n.ptr<float>(r), (size_t)cols * 4);
+            if (!write_all(argv[8], out.data(), out.size() * 4)) return 10;
+            const double range[2] = {0, 80};
+            dcmt_shim::interpolate_with_labels(clusters, n_labels, sparse, dense_n, "gaussian", 1, range);
+            for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], dense_n.ptr<float>(r), (size_t)cols * 4);
+            if (!write_all(argv[9], out.data(), out.size() * 4)) return 11;
+        }
     }
     std::printf("shim ok\n");
     return 0;

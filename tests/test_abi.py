@@ -34,7 +34,7 @@ def test_code_object_targets_gfx950_only():
 
 
 def test_params_struct_layout_matches_header():
-    assert ctypes.sizeof(L.Params) == 4 + 4 + 25 + 3 + 6 * 4
+    assert ctypes.sizeof(L.Params) == 4 + 4 + 25 + 3 + 6 * 4 + 2 * 4
     p = api.make_params()
     assert p.max_depth == 100.0
     assert np.float32(p.valid_thresh) == np.float32(0.1)
@@ -43,6 +43,9 @@ def test_params_struct_layout_matches_header():
     want[1, 3] = want[4, 4] = 1
     assert np.array_equal(k, want)                      # as-compiled element (img_completion.cpp:71-77)
     assert p.blur == L.BLUR_GAUSSIAN and p.stop_after == L.STAGE_FINAL and p.max_fill_iters == 64
+    assert p.flags == 0 and (p.norm_lo, p.norm_hi) == (0.0, 100.0)      # SL/main_sl.cpp:370's range; off unless the flag is set
+    n = api.make_params(normalize=(0, 80))
+    assert n.flags == L.FLAG_NORMALIZE and (n.norm_lo, n.norm_hi) == (0.0, 80.0)
     d = api.make_params(k0="diamond")
     assert sum(bytes(d.k0)) == 13
     assert api.make_params(blur_type="bilateral").blur == L.BLUR_BILATERAL
@@ -50,7 +53,7 @@ def test_params_struct_layout_matches_header():
 
 
 def test_status_strings_and_version():
-    assert L.lib().dcmt_version() == 100
+    assert L.lib().dcmt_version() == 110
     for s in range(0, -7, -1):
         assert L.strerror(s) and L.strerror(s) != "unknown status"
     assert L.strerror(-99) == "unknown status"

@@ -328,3 +328,57 @@ def test_uint16_ingest(O):
             got = out.cpu().numpy()
         for i in (0, n - 1):
             assert_bit_equal(got[i], O.img_completion(as_f32[i]), f"u16 ingest n={n} frame {i}")
+
+
+NORM_TOL = 1e-5     # relative; only where the shift term is live (smin != 0): an FMA build of OpenCV rounds once, this path twice
+
+
+def test_n1_normalize_fused_in_front_of_the_path(ctx, golden, golden_meta, O):
+    """DCMT_FLAG_NORMALIZE = cv::normalize(NORM_MINMAX) + the path (SL/main_sl.cpp:370 -> img_completion,
+    :523 -> interpolate_with_superpixels).  Bit-exact against the goldens and the oracle on every dispatch path."""
+    x = golden["norm48x64_in"]
+    for fused in (False, True):
+        mk = lambda **kw: api.make_params(force_fused=fused, **kw)
+        assert_bit_equal(ctx.complete(x, mk(normalize=(0, 100), stop_after=L.STAGE_NORMALIZE)), golden["norm48x64_n100"], "normalised frame")
+        assert_bit_equal(ctx.complete(x, mk(normalize=(0, 100), stop_after=2)), golden["norm48x64_stage2_100"], "H2 of normalised frame")
+        assert_bit_equal(ctx.complete(x, mk(normalize=(0, 100))), golden["norm48x64_out100"], f"chain (0,100) fused={fused}")
+        assert_bit_equal(ctx.complete(x, mk(normalize=(100, 0))), golden["norm48x64_out100"], "argument order")
+        assert_bit_equal(ctx.complete(x, mk(normalize=(0, 80), k0="diamond")), golden["norm48x64_out80_diamond"], f"(0,80) diamond fused={fused}")
+        # labeled variant, as SL/main_sl.cpp:523-540 chains them
+        xl, lab, nl = golden["lc40x56_in"], golden["lc40x56_labels"], golden_meta["lc40x56_n_labels"]
+        assert_bit_equal(ctx.complete(xl, mk(normalize=(0, 80)), labels=lab, n_labels=nl), golden["norm_lc40x56_out80"], f"LC (0,80) fused={fused}")
+        # smin != 0 (no empty pixel, a negative value): still the oracle's bits; the stated tolerance is for other OpenCV builds
+        xd = golden["norm_dense40x56_in"]
+        got = ctx.complete(xd, mk(normalize=(0, 80), stop_after=L.STAGE_NORMALIZE))
+        assert_bit_equal(got, golden["norm_dense40x56_n80"], "normalise, live shift")
+        ref64 = (xd.astype(np.float64) - xd.min()) * (80.0 / (float(xd.max()) - float(xd.min())))
+        assert np.abs(got - ref64).max() <= NORM_TOL * 80.0
+        assert_bit_equal(ctx.complete(xd, mk(normalize=(0, 80))), golden["norm_dense40x56_out80"], f"chain, live shift fused={fused}")
+        flat = ctx.complete(np.full((8, 8), 2.0, np.float32), mk(normalize=(5, 80), stop_after=L.STAGE_NORMALIZE))
+        assert_bit_equal(flat, golden["norm_flat_n"], "flat frame")
+    # config 4 shape, frames with different extrema in one device batch (per-frame coefficients), both presets
+    import torch
+    n = 16
+    frames = synth.synth_batch(n, 375, 1242, 700) * np.linspace(0.5, 1.5, n, dtype=np.float32)[:, None, None]
+    with api.Context(0, 375, 1242, n) as c:
+        for k0 in ("as_compiled", "diamond"):
+            out = c.complete_dev(torch.from_numpy(frames).cuda(), params=api.make_params(normalize=(0, 80), k0=k0))
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for i in (0, 7, 15):
+                assert_bit_equal(got[i], O.img_completion(O.normalize_minmax(frames[i], 0, 80), O.default_params(k0=k0)), f"device batch frame {i} {k0}")
+        labs = np.stack([synth.synth_labels(375, 1242, 100, 700 + i)[0] for i in range(n)])
+        nl = synth.synth_labels(375, 1242, 100, 700)[1]
+        out = c.complete_dev(torch.from_numpy(frames).cuda(), params=api.make_params(normalize=(0, 80)),
+                             d_labels=torch.from_numpy(labs).cuda(), n_labels=nl)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in (0, 9):
+            assert_bit_equal(got[i], O.interpolate_with_superpixels(O.normalize_minmax(frames[i], 0, 80), labs[i], nl), f"LC device batch frame {i}")
+        # the two ingests are never combined by the reference: refused, not silently ignored
+        with pytest.raises(api.DcmtError) as e:
+            c.complete_u16_dev(torch.zeros((n, 375, 1242), dtype=torch.int16, device="cuda"), params=api.make_params(normalize=(0, 80)))
+        assert e.value.status == L.E_UNSUPPORTED
+    with pytest.raises(api.DcmtError) as e:       # stage 1 only exists with the flag
+        ctx.complete(x, api.make_params(stop_after=L.STAGE_NORMALIZE))
+    assert e.value.status == L.E_INVALID

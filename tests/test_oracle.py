@@ -196,3 +196,24 @@ def test_batch_matches_single_and_threads():
     for i in range(3):
         assert_bit_equal(got1[i], O.img_completion(frames[i]), f"batch frame {i}")
     assert_bit_equal(got1, got2, "threads")
+
+
+def test_n1_normalize_goldens_and_known_answers(golden):
+    """N1 (cv::normalize NORM_MINMAX in front of the path, SL/main_sl.cpp:370 / :523): the C oracle against the
+    numpy restatement's goldens, and the properties the formula guarantees."""
+    from oracle import oracle as O
+    x = golden["norm48x64_in"]
+    n100 = O.normalize_minmax(x, 0, 100)
+    assert_bit_equal(n100, golden["norm48x64_n100"], "normalize (0,100)")
+    assert_bit_equal(O.img_completion(n100), golden["norm48x64_out100"], "chain on normalised frame")
+    assert_bit_equal(O.img_completion(n100, O.default_params(stop_after=2)), golden["norm48x64_stage2_100"], "H2 on normalised frame")
+    assert_bit_equal(O.img_completion(O.normalize_minmax(x, 0, 80), O.default_params(k0="diamond")), golden["norm48x64_out80_diamond"], "(0,80) diamond")
+    xd = golden["norm_dense40x56_in"]
+    assert_bit_equal(O.normalize_minmax(xd, 0, 80), golden["norm_dense40x56_n80"], "normalize with smin != 0")
+    assert_bit_equal(O.normalize_minmax(np.full((8, 8), 2.0, np.float32), 5, 80), golden["norm_flat_n"], "flat frame")
+    # empty pixels stay exactly 0 (shift == 0), the maximum lands within one rounding of `hi`, the argument order is irrelevant
+    assert (n100[x == 0] == 0).all() and abs(float(n100.max()) - 100.0) <= 1e-5
+    assert_bit_equal(O.normalize_minmax(x, 100, 0), n100, "cv::normalize takes min/max of (alpha, beta)")
+    assert (golden["norm_flat_n"] == 5.0).all()                 # smax - smin <= DBL_EPSILON: scale 0, everything = dmin
+    # scaling by a power of two commutes exactly with the normalisation
+    assert_bit_equal(O.normalize_minmax(x * np.float32(4.0), 0, 100), n100, "power-of-two input scale")

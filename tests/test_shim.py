@@ -26,7 +26,8 @@ def test_cpp_caller_matches_oracle(tmp_path):
     x.tofile(tmp_path / "in.f32")
     lab.tofile(tmp_path / "lab.i32")
     r = subprocess.run([os.path.join(ROOT, "tests", "mock_opencv", "shim_test"), str(rows), str(cols), str(tmp_path / "in.f32"),
-                        str(tmp_path / "out.f32"), str(tmp_path / "lab.i32"), str(nl), str(tmp_path / "out_lc.f32")],
+                        str(tmp_path / "out.f32"), str(tmp_path / "lab.i32"), str(nl), str(tmp_path / "out_lc.f32"),
+                        str(tmp_path / "out_n100.f32"), str(tmp_path / "out_lc_n80.f32")],
                        capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "NUMERO ROWS, COLS: 352 1216" in r.stdout          # the reference prints this (img_completion.cpp:29)
@@ -34,3 +35,7 @@ def test_cpp_caller_matches_oracle(tmp_path):
     assert_bit_equal(got, O.img_completion(x), "C++ img_completion")
     got_lc = np.fromfile(tmp_path / "out_lc.f32", dtype=np.float32).reshape(rows, cols)
     assert_bit_equal(got_lc, O.interpolate_with_superpixels(x, lab, nl), "C++ interpolate_with_superpixels")
+    got_n = np.fromfile(tmp_path / "out_n100.f32", dtype=np.float32).reshape(rows, cols)
+    assert_bit_equal(got_n, O.img_completion(O.normalize_minmax(x, 0, 100)), "C++ normalize + img_completion")
+    got_n = np.fromfile(tmp_path / "out_lc_n80.f32", dtype=np.float32).reshape(rows, cols)
+    assert_bit_equal(got_n, O.interpolate_with_superpixels(O.normalize_minmax(x, 0, 80), lab, nl), "C++ normalize + interpolate_with_superpixels")
