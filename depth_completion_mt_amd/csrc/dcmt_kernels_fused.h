@@ -45,6 +45,27 @@ __device__ __forceinline__ float hmin3(float v) { const float a = fmin2(from_lef
 __device__ __forceinline__ float hgrow_max(float w) { const float l = from_left(w); return fmax2(from_right(w), l); }
 __device__ __forceinline__ float hgrow_min(float w) { const float l = from_left(w); return fmin2(from_right(w), l); }
 
+// One frame as a buffer resource: rows are addressed as (per-lane 32-bit byte offset in a VGPR) + (wave-uniform row
+// byte offset in an SGPR) -- buffer_load_dword v, v_off, s[rsrc], s_row offen -- so a row access costs no VALU
+// address arithmetic at all (a flat global access spends one 64-bit per-lane add per row) and the lane offsets need
+// one VGPR each instead of a 64-bit pointer pair.  Raw buffer, stride 0, num_records = the frame's bytes.
+struct FrameBuf {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ void init(const float* frame, size_t elems)
+    {
+        const size_t bytes = elems * sizeof(float);
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(frame), 0, bytes > 0x7fffffffu ? 0x7fffffff : (int)bytes, 0x00020000);
+    }
+    __device__ __forceinline__ float ld(unsigned lane_bytes, int row, int cols) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_bytes, row * cols * 4, 0));
+    }
+    __device__ __forceinline__ void st(unsigned lane_bytes, int row, int cols, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, lane_bytes, row * cols * 4, 0);
+    }
+};
+
 // compile-time loop: f(std::integral_constant<int, P>) for P in [B, E)
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -522,15 +543,17 @@ struct PostPipe {
     float C[6];              // middle order statistics of the current 4-row core
     float G1[8], MR[8];      // horizontal Gaussian / median rows, slot (image row) & 7
     // per-lane constants
-    float* op;               // output column of this lane
+    FrameBuf of;             // output frame
+    unsigned ob;             // byte offset of this lane's (clamped) column
     int rows, cols, gx, rl;
     bool outlane, edge_strip;
     float max_depth, thr;
 
-    __device__ __forceinline__ void init(float* out_col, int rows_, int cols_, int gx0, int lane, float max_depth_, float thr_)
+    __device__ __forceinline__ void init(float* out_frame, int rows_, int cols_, int gx0, int lane, float max_depth_, float thr_)
     {
-        op = out_col; rows = rows_; cols = cols_; max_depth = max_depth_; thr = thr_;
+        of.init(out_frame, (size_t)rows_ * cols_); rows = rows_; cols = cols_; max_depth = max_depth_; thr = thr_;
         gx = gx0 + lane;
+        ob = 4u * (unsigned)min(max(gx, 0), cols - 1);
         outlane = gx >= 0 && gx < cols && lane >= PostS::H && lane < 64 - PostS::H;
         rl = reflect101(gx, cols) - gx0;      // reflect-101 source lane for the Gaussian's out-of-image columns
         edge_strip = gx0 < 0 || gx0 + 63 >= cols;
@@ -573,7 +596,7 @@ struct PostPipe {
         }
         const int j = u - 4;                                           // image row of this median
         if constexpr (MODE == 9) {
-            if ((unsigned)j < (unsigned)rows && outlane) op[(size_t)j * cols] = m;
+            if ((unsigned)j < (unsigned)rows && outlane) of.st(ob, j, cols, m);
             return;
         }
         MR[(PP + 4) & 7] = m;
@@ -610,7 +633,7 @@ struct PostPipe {
                 if (mo >= thr) val = acc;                               // LO :184
             }
             if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
-            if (outlane) op[(size_t)o * cols] = val;
+            if (outlane) of.st(ob, o, cols, val);
         }
     }
 };
@@ -634,16 +657,18 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
     const size_t fo = (size_t)f * rows * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
     const int gxc = min(max(gx0 + lane, 0), cols - 1);               // BORDER_REPLICATE for the median
-    const float* sp = ((a & 1) ? pp1 : pp0) + fo + gxc;
+    FrameBuf sf;
+    sf.init(((a & 1) ? pp1 : pp0) + fo, (size_t)rows * cols);
+    const unsigned sb = 4u * (unsigned)gxc;
     PostPipe<MODE, BLUR> pipe;
-    pipe.init(dst + fo + gxc, rows, cols, gx0, lane, max_depth, thr);
+    pipe.init(dst + fo, rows, cols, gx0, lane, max_depth, thr);
 
     float PF[8];
     constexpr int PFD = 4;
 #pragma unroll
     for (int q = 0; q < 8; ++q) PF[q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - 2, 0), rows - 1) * cols];
+    for (int q = 0; q < PFD; ++q) PF[q] = sf.ld(sb, min(max(q - 2, 0), rows - 1), cols);
 
     const int nsteps = rows + 6;                 // the last output row o = t - 6 = rows - 1
     for (int t0 = 0; t0 < nsteps; t0 += 8) {
@@ -651,7 +676,7 @@ void k_post_s(const float* __restrict__ pp0, const float* __restrict__ pp1, floa
             constexpr int p = decltype(P_)::value;
             const int t = t0 + p;
             const float x = PF[p];
-            PF[(p + PFD) & 7] = sp[(size_t)min(max(t + PFD - 2, 0), rows - 1) * cols];
+            PF[(p + PFD) & 7] = sf.ld(sb, min(max(t + PFD - 2, 0), rows - 1), cols);
             pipe.template step<p>(x, t);
         });
     }
@@ -694,6 +719,18 @@ DCMT_MAX_DPP(max_shl1, "row_shl:1") DCMT_MAX_DPP(max_shl2, "row_shl:2") DCMT_MAX
 #undef DCMT_MAX_DPP
 __device__ __forceinline__ float row_prefix_max(float x) { max_shr1(x); max_shr2(x); max_shr4(x); max_shr8(x); return x; }
 __device__ __forceinline__ float row_suffix_max(float x) { max_shl1(x); max_shl2(x); max_shl4(x); max_shl8(x); return x; }
+// Three scans at once (prefix of a, suffix of a, prefix of b), their steps interleaved: every DPP read is two
+// instructions behind the write of its source, which is exactly the two wait states the hazard needs, so the whole
+// block carries one s_nop instead of twelve.
+__device__ __forceinline__ void row_scans3(float a, float b, float& pa, float& sa, float& pb)
+{
+    pa = a; sa = a; pb = b;
+#define DCMT_S3(SH, N) "v_max_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                       "v_max_f32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                       "v_max_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" DCMT_S3(, 1) DCMT_S3(, 2) DCMT_S3(, 4) DCMT_S3(, 8) : "+v"(pa), "+v"(sa), "+v"(pb));
+#undef DCMT_S3
+}
 
 __global__ __launch_bounds__(256)
 void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
@@ -817,8 +854,10 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     // in DESCENDING order (lane 49 = gx0-1 ... lane 63 = gx0-15; lane 48 duplicates gx0-1), so that the
     // suffix the left side needs is a PREFIX over lanes too and one row scan serves both halos
     const int gxb = lane <= 14 ? gx0 + 64 + lane : (lane >= 49 ? gx0 + 48 - lane : (lane == 48 ? gx0 - 1 : gxa));
-    const float* spa = x6 + fo + min(max(gxa, 0), cols - 1);       // clamped: replicate == constant border for a max filter
-    const float* spb = x6 + fo + min(max(gxb, 0), cols - 1);
+    FrameBuf sf;
+    sf.init(x6 + fo, (size_t)rows * cols);
+    const unsigned sba = 4u * (unsigned)min(max(gxa, 0), cols - 1);   // clamped: replicate == constant border for a max filter
+    const unsigned sbb = 4u * (unsigned)min(max(gxb, 0), cols - 1);
     const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
     const unsigned long long own_mask = __ballot(own);          // wave-uniform: the hole counts stay on the scalar unit
     const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
@@ -830,7 +869,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     const int lb = lane <= 14 ? lane : (lane >= 48 ? lane - 32 : 15);   // B's live lanes 0..14, 48..63 -> words 0..14, 16..31; the dead lanes share word 15
 
     PostPipe<11, BLUR> pipe;
-    pipe.init(dst + fo + min(max(gxa, 0), cols - 1), rows, cols, gx0, lane, max_depth, thr);
+    pipe.init(dst + fo, rows, cols, gx0, lane, max_depth, thr);
 
     constexpr float NEG = -FLT_MAX;
     float PFA[16], PFB[16], W2A[16], W4A[16], W8A[16], W2B[16], W4B[16], W8B[16], DL[8];
@@ -843,10 +882,10 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     constexpr int PFD = 4;
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
-        const size_t ro = (size_t)min(max(q - 15, 0), rows - 1) * cols;
-        PFA[q] = spa[ro]; PFB[q] = spb[ro];
+        const int row = min(max(q - 15, 0), rows - 1);
+        PFA[q] = sf.ld(sba, row, cols); PFB[q] = sf.ld(sbb, row, cols);
     }
-    float vpa = NEG, vpb = NEG, x7_first = 0.f, x7_last = 0.f;
+    float vpa = NEG, vpb = NEG, x7_prev = 0.f;
     int before = 0, after = 0;
     // Software skew: the two ds_bpermutes and the two delay-line reads issued in step t are consumed
     // in step t + 1, so their LDS round trips overlap the next step's arithmetic instead of
@@ -859,8 +898,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         constexpr int p = decltype(P_)::value;
         const float xa = PFA[p], xb = PFB[p];
         {
-            const size_t ro = (size_t)min(max(t + PFD - 15, 0), rows - 1) * cols;
-            PFA[(p + PFD) & 15] = spa[ro]; PFB[(p + PFD) & 15] = spb[ro];
+            const int row = min(max(t + PFD - 15, 0), rows - 1);
+            PFA[(p + PFD) & 15] = sf.ld(sba, row, cols); PFB[(p + PFD) & 15] = sf.ld(sbb, row, cols);
         }
         // finish row t - 1 - 30 from what step t - 1 left pending
         const float d = fmax3(pend_m, pend_slo, pend_phi);
@@ -872,8 +911,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             after += __builtin_popcountll(__ballot(x7 < thr) & own_mask);
         }
         if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
-        if (o == 0) x7_first = x7;
-        if (o == rows - 1) x7_last = x7;
+        if (o >= rows) x7 = x7_prev;                                // rows below the image replicate the last row (median border)
+        x7_prev = x7;
         // vertical 31-max, both registers (see k_fill_s)
         const float w2a = fmax2(xa, vpa), w2b = fmax2(xb, vpb);
         vpa = xa; vpb = xb;
@@ -897,8 +936,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         // replaces holes (x < thr), so a row in which none of this wave's 64 columns is a hole needs no
         // horizontal maximum at all (wave-uniform skip; the vertical state above is always kept current).
         if (__ballot(v < thr) != 0ull) {
-            const float PA = row_prefix_max(w31a), SA = row_suffix_max(w31a);
-            const float PB = row_prefix_max(w31b);
+            float PA, SA, PB;
+            row_scans3(w31a, w31b, PA, SA, PB);
             const float Sm = lane >= 49 ? PB : SA, Pm = lane <= 14 ? PB : PA;   // lane 48 of S' is still S_A(48), needed by c = 63
             pend_slo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_lo, __builtin_bit_cast(int, Sm)));
             pend_phi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a_hi, __builtin_bit_cast(int, Pm)));
@@ -915,6 +954,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             DL[p & 7] = fill_step(P_, t0 + p);
         });
     }
+    DL[5] = DL[6] = DL[7];                       // rows -2, -1 replicate row 0 (step 31 left X7 row 0 in DL[7])
     // steps 32..rows+37: fill + post; post step u = t - 32 takes X7 row clamp(u - 2) = clamp(t - 34),
     // which the fill front end produced 3 steps ago
     const int nsteps = rows + 38;
@@ -923,10 +963,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             constexpr int p = decltype(P_)::value;
             const int t = t0 + p, u = t - FpS::LAG;
             DL[p & 7] = fill_step(P_, t);
-            float xin = DL[(p + 5) & 7];
-            if (u < 2) xin = x7_first;                              // replicated rows
-            if (u - 2 >= rows) xin = x7_last;
-            pipe.template step<(p & 7)>(xin, u);
+            pipe.template step<(p & 7)>(DL[(p + 5) & 7], u);
         });
     }
     if (lane == 0) {
