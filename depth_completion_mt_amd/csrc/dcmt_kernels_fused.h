@@ -64,6 +64,11 @@ struct FrameBuf {
     {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, lane_bytes, row * cols * 4, 0);
     }
+    // per-lane rows: the whole byte offset in the VGPR
+    __device__ __forceinline__ float ld_at(unsigned bytes) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, bytes, 0, 0));
+    }
 };
 
 // compile-time loop: f(std::integral_constant<int, P>) for P in [B, E)
@@ -208,7 +213,9 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
         if constexpr (U16) return __fmul_rn((float)sp16[(size_t)r * cols], in_scale);
         else return sp[(size_t)r * cols];
     };
-    float* op = x6 + fo + gxc;
+    FrameBuf ob;                                  // the output frame; this lane's column at byte offset oc
+    ob.init(x6 + fo, (size_t)rows * cols);
+    const unsigned oc = 4u * (unsigned)gxc;
     RowRing<4, ROFF> rr;
     if constexpr (WIDE) rr.init(s_ring + (strip & 3) * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
 
@@ -299,22 +306,22 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
                 ti = min(ti, valid ? m : 0x7fffffff);
                 bi = valid ? m : bi;
                 // rows above the first valid one are written by the epilogue
-                if (outlane && m >= ti) op[(size_t)m * cols] = x5;
+                if (outlane && m >= ti) ob.st(oc, m, cols, x5);
             }
         }
     }
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
     // value; a column without valid pixels ends as 100 everywhere (:110, :125-127)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's own stores, before it reads two of them back
-    float tv = op[(size_t)min(ti, rows - 1) * cols], bv = op[(size_t)max(bi, 0) * cols];
+    float tv = ob.ld_at(oc + 4u * (unsigned)(min(ti, rows - 1) * cols)), bv = ob.ld_at(oc + 4u * (unsigned)(max(bi, 0) * cols));
     if (bi < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
     if (!outlane) { ti = -1; bi = rows; }
     const int tmax = wave_max_i(ti);
     for (int r = 0; r <= tmax; ++r)
-        if (r <= ti) op[(size_t)r * cols] = tv;
+        if (r <= ti) ob.st(oc, r, cols, tv);
     const int bmin = wave_min_i(bi);
     for (int r = bmin; r < rows; ++r)
-        if (r >= bi) op[(size_t)r * cols] = bv;
+        if (r >= bi) ob.st(oc, r, cols, bv);
 }
 
 // ---------------------------------------------------------------------------------
@@ -879,7 +886,10 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     for (int q = 0; q < 8; ++q) DL[q] = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { dl_c[q][lane] = NEG; dl_a[q][lane] = NEG; dl_b[q][lb] = NEG; }
-    constexpr int PFD = 4;
+#ifndef DCMT_FP_PFD
+#define DCMT_FP_PFD 4
+#endif
+    constexpr int PFD = DCMT_FP_PFD;         // rows of load lookahead
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
         const int row = min(max(q - 15, 0), rows - 1);
@@ -891,6 +901,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     // in step t + 1, so their LDS round trips overlap the next step's arithmetic instead of
     // stalling the wave (s_waitcnt) three times per step.
     float pend_m = NEG, pend_v = NEG, pend_slo = NEG, pend_phi = NEG;   // of stream row t - 1
+    unsigned long long pend_hm = 0;                                      // its hole mask (wave-uniform, lives in SGPRs)
     float nxt_c = NEG, nxt_a = NEG, nxt_b = NEG;                         // delay-line values for the next step
 
     // the fill front end of step t: returns X7 of image row t - 31 for every lane
@@ -903,12 +914,12 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         }
         // finish row t - 1 - 30 from what step t - 1 left pending
         const float d = fmax3(pend_m, pend_slo, pend_phi);
-        const bool hole = pend_v < thr;                             // LO :140
+        const bool hole = __builtin_amdgcn_inverse_ballot_w64(pend_hm);   // pend_v < thr, LO :140
         float x7 = hole ? d : pend_v;
         const int o = t - 31;
         if ((unsigned)o < (unsigned)rows) {                         // hole counts on the scalar unit: ballot + s_bcnt1
-            before += __builtin_popcountll(__ballot(hole) & own_mask);
-            after += __builtin_popcountll(__ballot(x7 < thr) & own_mask);
+            before += __builtin_popcountll(pend_hm & own_mask);
+            after += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x7 < thr) & own_mask);
         }
         if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
         if (o >= rows) x7 = x7_prev;                                // rows below the image replicate the last row (median border)
@@ -935,7 +946,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         // horizontal 31-max: scans now, the cross-row fetches land during the next step.  The fill only
         // replaces holes (x < thr), so a row in which none of this wave's 64 columns is a hole needs no
         // horizontal maximum at all (wave-uniform skip; the vertical state above is always kept current).
-        if (__ballot(v < thr) != 0ull) {
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(v < thr);
+        if (vm != 0ull) {
             float PA, SA, PB;
             row_scans3(w31a, w31b, PA, SA, PB);
             const float Sm = lane >= 49 ? PB : SA, Pm = lane <= 14 ? PB : PA;   // lane 48 of S' is still S_A(48), needed by c = 63
@@ -944,6 +956,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             pend_m = fmax2(PA, SA);
         }
         pend_v = v;
+        pend_hm = vm;
         return x7;
     };
 
