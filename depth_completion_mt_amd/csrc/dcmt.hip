@@ -50,6 +50,7 @@ struct dcmt_ctx {
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
+    int label_pairs = -1;             // LC fast path: one wave per label pair (1), per label (0), by label size (-1); env DCMT_LABEL_PAIRS
     int min_fused_batch = 12;         // smaller batches use the staged kernels (measured crossover: tools/batch_sweep.py); env DCMT_MIN_FUSED_BATCH
 };
 
@@ -323,11 +324,16 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             else
                 hipLaunchKernelGGL(k_label_bbox<false>, bg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
                                    rows, cols, p->max_depth, p->valid_thresh, coef);
-            const dim3 lg((n_labels + 3) / 4, batch);
-#define DCMT_LSTAGE(KIND, NORM) hipLaunchKernelGGL((k_label_stage_s<KIND, NORM>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, \
-                                                   ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef)
-            if (kind == K0_AS_COMPILED) { if (coef) DCMT_LSTAGE(K0_AS_COMPILED, true); else DCMT_LSTAGE(K0_AS_COMPILED, false); }
-            else { if (coef) DCMT_LSTAGE(K0_DIAMOND, true); else DCMT_LSTAGE(K0_DIAMOND, false); }
+            // labels of about 22 columns or less (the mean box of an even partition, with SLIC-like slack) can share a
+            // wave: one wave per label PAIR; few large labels: one wave per label (see k_label_stage_s)
+            const bool pairs = ctx->label_pairs >= 0 ? ctx->label_pairs != 0 : (double)rows * cols / n_labels <= 22.0 * 22.0;
+            const dim3 lg(pairs ? (n_labels + 7) / 8 : (n_labels + 3) / 4, batch);
+#define DCMT_LSTAGE(KIND, NORM) { if (pairs) hipLaunchKernelGGL((k_label_stage_s<KIND, NORM, true>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, \
+                                                   ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef); \
+                                  else hipLaunchKernelGGL((k_label_stage_s<KIND, NORM, false>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, \
+                                                   ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef); }
+            if (kind == K0_AS_COMPILED) { if (coef) DCMT_LSTAGE(K0_AS_COMPILED, true) else DCMT_LSTAGE(K0_AS_COMPILED, false) }
+            else { if (coef) DCMT_LSTAGE(K0_DIAMOND, true) else DCMT_LSTAGE(K0_DIAMOND, false) }
 #undef DCMT_LSTAGE
             DCMT_HIP(ctx, hipGetLastError());
             if (stop == DCMT_STAGE_CLOSE5) {
@@ -525,6 +531,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
     { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_LABEL_PAIRS"); if (e) ctx->label_pairs = std::atoi(e); }
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;

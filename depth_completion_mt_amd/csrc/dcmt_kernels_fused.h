@@ -69,6 +69,10 @@ struct FrameBuf {
     {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, bytes, 0, 0));
     }
+    __device__ __forceinline__ void st_at(unsigned bytes, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, bytes, 0, 0);
+    }
 };
 
 // compile-time loop: f(std::integral_constant<int, P>) for P in [B, E)
@@ -390,84 +394,126 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
     }
 }
 
-template <int K0KIND, bool NORM>
+// The masked pipeline of one label (or of two labels side by side) down the rows of its box.  L, y0, y1, gx and
+// outlane may be wave-uniform (one label per wave: the compiler keeps them on the scalar unit) or differ between
+// the two lane segments of a packed wave; nsteps is always uniform.
+template <int K0KIND, bool NORM, typename IntT>
+__device__ __forceinline__ void label_pipeline(const FrameBuf& sb, const FrameBuf& lb, const FrameBuf& ob, IntT L, IntT y0, IntT y1, int gx,
+                                               bool outlane, int nsteps, int rows, int cols, float max_depth, float thr, float na, float nb)
+{
+    constexpr int H = 6;                           // rows of reach above and below (H3 + H4)
+    constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
+    const bool incol = gx >= 0 && gx < cols;
+    const unsigned gb = 4u * (unsigned)min(max(gx, 0), cols - 1);
+    auto row_off = [&](IntT r) -> unsigned { return gb + 4u * (unsigned)(min(max(r, (IntT)0), (IntT)(rows - 1)) * cols); };
+    float PF[8], XR[8], A3[8], S1[8], H4[8], HE[8];
+    int PL[8], LB[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { PF[q] = 0.f; XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; PL[q] = -1; LB[q] = -1; }
+    const IntT rs = y0 - H;                        // image row of step 0
+    constexpr int PFD = 4;
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) {
+        const unsigned ro = row_off(rs + q);
+        PF[q] = sb.ld_at(ro); PL[q] = __builtin_bit_cast(int, lb.ld_at(ro));
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const IntT i = rs + (s0 + p);            // image row fed by this step
+            const float raw = PF[p];
+            const int lab = PL[p];
+            {
+                const unsigned ro = row_off(i + PFD);
+                PF[(p + PFD) & 7] = sb.ld_at(ro); PL[(p + PFD) & 7] = __builtin_bit_cast(int, lb.ld_at(ro));
+            }
+            LB[p] = lab;
+            // masked copy (LC :94-95): the label's pixels keep their H2 value, other image pixels are 0;
+            // outside the image the dilate border value
+            const bool inimg = incol && (unsigned)i < (unsigned)rows;
+            const float x2 = inimg ? (lab == L ? invert_valid(NORM ? norm_apply(raw, na, nb) : raw, max_depth, thr) : 0.0f) : NEG;
+            const IntT j = i - 2;
+            float y3;
+            if constexpr (K0KIND == K0_AS_COMPILED) {
+                const float s1 = from_right(x2);
+                const float s2 = from_right(s1);
+                S1[p] = s1;
+                y3 = fmax2(S1[(p + 5) & 7], s2);
+            } else {
+                const float a3 = hmax3(x2);
+                XR[p] = x2;
+                A3[p] = a3;
+                const float a5j = hgrow_max(A3[(p + 6) & 7]);
+                y3 = fmax2(fmax3(XR[(p + 4) & 7], A3[(p + 5) & 7], a5j), fmax2(A3[(p + 7) & 7], x2));
+            }
+            y3 = (incol && (unsigned)j < (unsigned)rows) ? y3 : NEG;
+            H4[(p + 6) & 7] = hgrow_max(hmax3(y3));
+            const IntT k = i - 4;
+            float d4 = fmax3(fmax3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
+            d4 = (incol && (unsigned)k < (unsigned)rows) ? d4 : POS;
+            HE[(p + 4) & 7] = hgrow_min(hmin3(d4));
+            const IntT l = i - 6;
+            const float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+            // write-back only where the label is this one (LC :101)
+            if (l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) ob.st_at(gb + 4u * (unsigned)(l * cols), e4);
+        }
+    }
+}
+
+// PAIRS: one wave64 per pair of labels (2w, 2w+1).  The chain's horizontal reach is HL columns to the left and HR
+// to the right (as-compiled element: 4 / 6, diamond: 6 / 6).  If both boxes, each grown by that halo, fit side by
+// side in the wave's 64 lanes, they run as two lane segments of ONE pass -- lanes carry their own label, box and
+// image row, and the DPP shifts that cross the segment boundary only ever reach halo lanes; superpixel boxes are
+// ~20 columns wide, so a lone box leaves two thirds of the wave idle.  A pair that does not fit runs one label
+// after the other.  !PAIRS: one wave per label (the host picks this when the labels are few and large: packing
+// cannot apply and twice as many, shorter waves fill the GPU better).  Boxes wider than VW = 64 - HL - HR
+// columns are walked in chunks.  Either mode is correct for any label plane; the choice only affects speed.
+template <int K0KIND, bool NORM, bool PAIRS>
 __global__ __launch_bounds__(256)
 void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
                      const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
                      int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
 {
-    constexpr int H = 6, VW = 64 - 2 * H;          // reach of H3 + H4 (diamond: 6 / 6), 52 output columns per chunk
-    constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
+    constexpr int HL = K0KIND == K0_AS_COMPILED ? 4 : 6, HR = 6, VW = 64 - HL - HR, H = 6;
     const int lane = threadIdx.x & 63;
-    const int L = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (L >= n_labels) return;
+    const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int La = PAIRS ? 2 * wv : wv, Lb = La + 1;
+    if (La >= n_labels) return;
     const int f = blockIdx.y;
-    const int y0 = bb_min[((size_t)f * n_labels + L) * 2], x0 = bb_min[((size_t)f * n_labels + L) * 2 + 1];
-    const int y1 = bb_max[((size_t)f * n_labels + L) * 2], x1 = bb_max[((size_t)f * n_labels + L) * 2 + 1];
-    if (y1 < 0) return;                            // the label owns no pixel
-    const size_t fo = (size_t)f * rows * cols;
+    const size_t bo = (size_t)f * n_labels;
+    const int y0a = bb_min[(bo + La) * 2], x0a = bb_min[(bo + La) * 2 + 1], y1a = bb_max[(bo + La) * 2], x1a = bb_max[(bo + La) * 2 + 1];
+    int y0b = 0, x0b = 0, y1b = -1, x1b = -1;
+    if (PAIRS && Lb < n_labels) { y0b = bb_min[(bo + Lb) * 2]; x0b = bb_min[(bo + Lb) * 2 + 1]; y1b = bb_max[(bo + Lb) * 2]; x1b = bb_max[(bo + Lb) * 2 + 1]; }
+    const bool ea = y1a >= 0, eb = y1b >= 0;     // a label may own no pixel
+    if (!ea && !eb) return;
+    const size_t fo = (size_t)f * rows * cols, fe = (size_t)rows * cols;
     float na = 1.0f, nb = 0.0f;                    // N1 normalisation
     if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
-    for (int cx = x0; cx <= x1; cx += VW) {
-        const int gx = cx - H + lane;
-        const bool incol = gx >= 0 && gx < cols;
-        const bool outlane = incol && lane >= H && lane < 64 - H && gx <= x1;
-        const int gxc = min(max(gx, 0), cols - 1);
-        const float* sp = src + fo + gxc;
-        const int32_t* lp = labels + fo + gxc;
-        float* op = x4 + fo + gxc;
-        float PF[8], XR[8], A3[8], S1[8], H4[8], HE[8];
-        int PL[8], LB[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { PF[q] = 0.f; XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; PL[q] = -1; LB[q] = -1; }
-        const int rs = y0 - H;                     // image row of step 0
-        constexpr int PFD = 4;
-#pragma unroll
-        for (int q = 0; q < PFD; ++q) {
-            const size_t ro = (size_t)min(max(rs + q, 0), rows - 1) * cols;
-            PF[q] = sp[ro]; PL[q] = lp[ro];
+    FrameBuf sb, lb, ob;
+    sb.init(src + fo, fe);
+    lb.init(reinterpret_cast<const float*>(labels + fo), fe);
+    ob.init(x4 + fo, fe);
+    if constexpr (PAIRS) {
+        const int wa = x1a - x0a + 1, wb = x1b - x0b + 1;
+        if (ea && eb && wa + wb + 2 * (HL + HR) <= 64) {
+            const int split = HL + wa + HR;        // first lane of the second segment
+            const bool second = lane >= split;
+            const int li = second ? lane - split : lane;
+            const int gx = (second ? x0b : x0a) - HL + li;
+            const bool outlane = gx >= 0 && gx < cols && li >= HL && li < HL + (second ? wb : wa);
+            const int ha = y1a - y0a, hb = y1b - y0b;
+            label_pipeline<K0KIND, NORM, int>(sb, lb, ob, second ? Lb : La, second ? y0b : y0a, second ? y1b : y1a, gx, outlane,
+                                              (ha > hb ? ha : hb) + 1 + 2 * H, rows, cols, max_depth, thr, na, nb);
+            return;
         }
-        const int nsteps = y1 - y0 + 1 + 2 * H;    // the last step finishes image row y1
-        for (int s0 = 0; s0 < nsteps; s0 += 8) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int i = rs + s0 + p;           // image row fed by this step
-                const float raw = PF[p];
-                const int lab = PL[p];
-                {
-                    const size_t ro = (size_t)min(max(i + PFD, 0), rows - 1) * cols;
-                    PF[(p + PFD) & 7] = sp[ro]; PL[(p + PFD) & 7] = lp[ro];
-                }
-                LB[p] = lab;
-                // masked copy (LC :94-95): the label's pixels keep their H2 value, other image pixels are 0;
-                // outside the image the dilate border value
-                const bool inimg = incol && (unsigned)i < (unsigned)rows;
-                const float x2 = inimg ? (lab == L ? invert_valid(NORM ? norm_apply(raw, na, nb) : raw, max_depth, thr) : 0.0f) : NEG;
-                const int j = i - 2;
-                float y3;
-                if constexpr (K0KIND == K0_AS_COMPILED) {
-                    const float s1 = from_right(x2);
-                    const float s2 = from_right(s1);
-                    S1[p] = s1;
-                    y3 = fmax2(S1[(p + 5) & 7], s2);
-                } else {
-                    const float a3 = hmax3(x2);
-                    XR[p] = x2;
-                    A3[p] = a3;
-                    const float a5j = hgrow_max(A3[(p + 6) & 7]);
-                    y3 = fmax2(fmax3(XR[(p + 4) & 7], A3[(p + 5) & 7], a5j), fmax2(A3[(p + 7) & 7], x2));
-                }
-                y3 = (incol && (unsigned)j < (unsigned)rows) ? y3 : NEG;
-                H4[(p + 6) & 7] = hgrow_max(hmax3(y3));
-                const int k = i - 4;
-                float d4 = fmax3(fmax3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
-                d4 = (incol && (unsigned)k < (unsigned)rows) ? d4 : POS;
-                HE[(p + 4) & 7] = hgrow_min(hmin3(d4));
-                const int l = i - 6;
-                const float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
-                // write-back only where the label is this one (LC :101)
-                if (l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) op[(size_t)l * cols] = e4;
-            }
+    }
+    for (int w = 0; w < (PAIRS ? 2 : 1); ++w) {
+        const int L = w ? Lb : La, y0 = w ? y0b : y0a, y1 = w ? y1b : y1a, x0 = w ? x0b : x0a, x1 = w ? x1b : x1a;
+        if (y1 < 0) continue;
+        for (int cx = x0; cx <= x1; cx += VW) {
+            const int gx = cx - HL + lane;
+            const bool outlane = gx >= 0 && gx < cols && lane >= HL && lane < HL + VW && gx <= x1;
+            label_pipeline<K0KIND, NORM, int>(sb, lb, ob, L, y0, y1, gx, outlane, y1 - y0 + 1 + 2 * H, rows, cols, max_depth, thr, na, nb);
         }
     }
 }

@@ -312,6 +312,33 @@ def test_dispatch_toggles_give_identical_results(O):
         assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_label_stage_wave_modes_give_identical_results():
+    """The label-masked stage runs one wave per label pair (two boxes side by side in one wave where they fit) or
+    one wave per label; the host picks by label size, DCMT_LABEL_PAIRS forces either.  Both must reproduce the
+    oracle on small (packable) and large (chunked) labels, for both structuring elements."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from depth_completion_mt_amd import Context, make_params, synth
+        from oracle import oracle as O
+        for rows, cols, nt in ((352, 1216, 1200), (375, 1242, 100), (200, 333, 40)):
+            x = synth.synth_frame(rows, cols, 77)
+            lab, nl = synth.synth_labels(rows, cols, nt, 77)
+            lab[lab == 3] = -1                      # an empty label inside a pair
+            with Context(0, rows, cols, 1) as ctx:
+                for k0 in ("as_compiled", "diamond"):
+                    got = ctx.complete(x, make_params(force_fused=True, k0=k0), labels=lab, n_labels=nl)
+                    ref = O.interpolate_with_superpixels(x, lab, nl, O.default_params(k0=k0))
+                    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (rows, cols, nt, k0)
+        print("OK")
+    """)
+    for env in ({"DCMT_LABEL_PAIRS": "0"}, {"DCMT_LABEL_PAIRS": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_uint16_ingest(O):
     """The reference's ingest (main.cpp:75-82: uint16 PNG payload, convertTo(CV_32F, 1/256)) fused into the first
     kernel: same bits as converting on the host and calling the f32 entry point -- streaming path (16 frames) and
