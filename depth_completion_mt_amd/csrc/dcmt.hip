@@ -316,9 +316,9 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_min, 0x7f, sizeof(int) * need, st));
             DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_max, 0xff, sizeof(int) * need, st));
             float* x4 = stop == DCMT_STAGE_CLOSE5 ? d_dst : ctx->pp[1];
-            const dim3 bg((cols + 63) / 64, (rows + 31) / 32, batch);
+            const dim3 bg((cols + 63) / 64, (rows + kBboxRows - 1) / kBboxRows, batch);
             const size_t table = sizeof(int) * 4 * (size_t)n_labels;
-            if (table <= 48 * 1024)
+            if (table <= 48 * 1024 && !std::getenv("DCMT_BBOX_GLOBAL"))
                 hipLaunchKernelGGL(k_label_bbox<true>, bg, dim3(256), table, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
                                    rows, cols, p->max_depth, p->valid_thresh, coef);
             else

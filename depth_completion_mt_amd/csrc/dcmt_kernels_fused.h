@@ -339,9 +339,10 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 //                    writes X4 where label == c.  Boxes wider than 52 columns are walked in chunks.
 //   k_pre_s<START4>  H5 + H6 on X4, then k_fp_s as for img_completion.
 // ---------------------------------------------------------------------------------
-// LDS_TABLE: the workgroup (64 columns x 32 rows) first reduces into a per-label table in LDS (ds_min /
+// LDS_TABLE: the workgroup (64 columns x kBboxRows rows) first reduces into a per-label table in LDS (ds_min /
 // ds_max, no global traffic) and then issues global atomics only for the handful of labels it touched;
 // without it (label tables too big for LDS) every run start / end goes to global memory directly.
+constexpr int kBboxRows = 128;               // rows per workgroup (32 per wave, in groups of 8): the table init / flush is paid once per 128 rows
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(256)
 void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
@@ -361,11 +362,21 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
         }
         __syncthreads();
     }
+    const bool in = gx < cols;
+    for (int g = 0; g < kBboxRows / 32; ++g) {
+    const int gy0 = blockIdx.y * kBboxRows + (g * 4 + wave) * 8;
+    if (gy0 >= rows) break;
+    int lrow[8];                                   // all eight label rows in flight before the first is looked at
+#pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const int gy = blockIdx.y * 32 + wave * 8 + r;
+        const int gy = gy0 + r;
+        lrow[r] = (in && gy < rows) ? labels[fo + (size_t)gy * cols + gx] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int gy = gy0 + r;
         if (gy >= rows) break;
-        const bool in = gx < cols;
-        int l = in ? labels[fo + (size_t)gy * cols + gx] : -1;
+        int l = lrow[r];
         const bool lv = in && l >= 0 && l < n_labels;
         if (!lv) l = -1;
         const int left = __builtin_amdgcn_update_dpp(-2, l, 0x138, 0xf, 0xf, false);   // lane 0 keeps -2: always a run start
@@ -382,6 +393,7 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
             if (coef) v = norm_apply(v, coef[2 * f], coef[2 * f + 1]);    // N1 normalisation, if any
             x4[fo + (size_t)gy * cols + gx] = invert_valid(v, max_depth, thr);
         }
+    }
     }
     if constexpr (LDS_TABLE) {
         __syncthreads();
