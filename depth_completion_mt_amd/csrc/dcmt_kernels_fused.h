@@ -681,24 +681,28 @@ struct PostPipe {
         if ((unsigned)o < (unsigned)rows) {
             // slots: row o -> (PP+2)&7, o+1 -> PP+3, o+2 -> PP+4, o-1 -> PP+1, o-2 -> PP
             const float mo = MR[(PP + 2) & 7];
-            float val = mo;
-            if constexpr (do_blur) {
-                const float g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7];
-                const float g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];
-                float u1 = g_m1, u2 = g_m2, d1 = g_p1, d2 = g_p2;
-                if (o < 2 || o + 2 >= rows) {                            // reflect-101 rows (rows >= 8 guaranteed)
-                    u1 = o >= 1 ? g_m1 : g_p1;
-                    u2 = o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2);
-                    d1 = o + 1 < rows ? g_p1 : g_m1;
-                    d2 = o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2);
+            // the rest of the row, given the four vertical neighbours of the horizontal pass
+            auto finish = [&](float u1, float u2, float d1, float d2) {
+                float val = mo;
+                if constexpr (do_blur) {
+                    float acc = __fmul_rn(G1[(PP + 2) & 7], 0.375f);
+                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
+                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
+                    if (mo >= thr) val = acc;                           // LO :184
                 }
-                float acc = __fmul_rn(g_0, 0.375f);
-                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
-                acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
-                if (mo >= thr) val = acc;                               // LO :184
+                if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
+                if (outlane) of.st(ob, o, cols, val);
+            };
+            const float g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7];
+            const float g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];
+            if (do_blur && (o < 2 || o + 2 >= rows)) {                    // reflect-101 rows (rows >= 8 guaranteed): the first and
+                finish(o >= 1 ? g_m1 : g_p1,                             // last two rows get their own copy of the tail, so the
+                       o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2),            // common path reads the ring registers in place
+                       o + 1 < rows ? g_p1 : g_m1,
+                       o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2));
+            } else {
+                finish(g_m1, g_m2, g_p1, g_p2);
             }
-            if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
-            if (outlane) of.st(ob, o, cols, val);
         }
     }
 };
@@ -971,13 +975,16 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             PFA[(p + PFD) & 15] = sf.ld(sba, row, cols); PFB[(p + PFD) & 15] = sf.ld(sbb, row, cols);
         }
         // finish row t - 1 - 30 from what step t - 1 left pending
-        const float d = fmax3(pend_m, pend_slo, pend_phi);
-        const bool hole = __builtin_amdgcn_inverse_ballot_w64(pend_hm);   // pend_v < thr, LO :140
-        float x7 = hole ? d : pend_v;
         const int o = t - 31;
-        if ((unsigned)o < (unsigned)rows) {                         // hole counts on the scalar unit: ballot + s_bcnt1
-            before += __builtin_popcountll(pend_hm & own_mask);
-            after += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x7 < thr) & own_mask);
+        float x7 = pend_v;
+        if (pend_hm != 0ull) {                                      // a row without holes passes through untouched
+            const float d = fmax3(pend_m, pend_slo, pend_phi);
+            const bool hole = __builtin_amdgcn_inverse_ballot_w64(pend_hm);   // pend_v < thr, LO :140
+            x7 = hole ? d : pend_v;
+            if ((unsigned)o < (unsigned)rows) {                     // hole counts on the scalar unit: ballot + s_bcnt1
+                before += __builtin_popcountll(pend_hm & own_mask);
+                after += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x7 < thr) & own_mask);
+            }
         }
         if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
         if (o >= rows) x7 = x7_prev;                                // rows below the image replicate the last row (median border)
