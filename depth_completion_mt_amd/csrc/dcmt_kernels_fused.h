@@ -592,6 +592,16 @@ __device__ __forceinline__ float final6(const float (&C)[6], const float (&a)[5]
                  fmin3(fmax2(a[2], C[2]), fmax2(a[3], C[1]), fmax2(a[4], C[0])));
 }
 
+// One pass of the [1 4 6 4 1]/16 filter in the reference order  c*k0 + s1*k1 + s2*k2  (s1, s2 = the already rounded
+// sums of the two neighbour pairs; every product rounded, the sum taken left to right).  k1 = 1/4 and k2 = 1/16 are
+// powers of two, so those two products are exact and folding them into fused multiply-adds changes no rounding:
+// round(a + exact(s*k)) is what the unfused sequence computes too.  (The one exception is a product that underflows
+// into a subnormal and loses bits there, |s| < 2^-122 -- forty orders of magnitude below a depth in metres.)
+__device__ __forceinline__ float gauss_taps(float c, float s1, float s2)
+{
+    return __builtin_fmaf(s2, 0.0625f, __builtin_fmaf(s1, 0.25f, __fmul_rn(c, 0.375f)));
+}
+
 // The streaming post pipeline (H9..H11) of one wave: state + one step.  Shared by k_post_s
 // (input rows from global memory) and k_fp_s (input rows straight from the fill stage).
 // MODE (9/10/11) and BLUR are compile-time: a run-time branch around the ring updates would
@@ -671,10 +681,7 @@ struct PostPipe {
             if (edge_strip) { const float mr = __shfl(m, rl, 64); mf = (gx < 0 || gx >= cols) ? mr : m; }
             const float ml1 = from_left(mf), mr1 = from_right(mf);
             const float ml2 = from_left(ml1), mr2 = from_right(mr1);
-            float acc = __fmul_rn(mf, 0.375f);
-            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml1, mr1), 0.25f));
-            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(ml2, mr2), 0.0625f));
-            G1[(PP + 4) & 7] = acc;
+            G1[(PP + 4) & 7] = gauss_taps(mf, __fadd_rn(ml1, mr1), __fadd_rn(ml2, mr2));
         }
         // ---- vertical pass + select + invert for output row o = j - 2 = u - 6
         const int o = u - 6;
@@ -685,9 +692,7 @@ struct PostPipe {
             auto finish = [&](float u1, float u2, float d1, float d2) {
                 float val = mo;
                 if constexpr (do_blur) {
-                    float acc = __fmul_rn(G1[(PP + 2) & 7], 0.375f);
-                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u1, d1), 0.25f));
-                    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(u2, d2), 0.0625f));
+                    const float acc = gauss_taps(G1[(PP + 2) & 7], __fadd_rn(u1, d1), __fadd_rn(u2, d2));
                     if (mo >= thr) val = acc;                           // LO :184
                 }
                 if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
