@@ -26,7 +26,7 @@ EXPORTS = (
     "dcmt_device_count", "dcmt_create", "dcmt_destroy", "dcmt_default_params", "dcmt_k0_as_compiled",
     "dcmt_k0_diamond", "dcmt_complete_f32", "dcmt_complete_f32_dev", "dcmt_complete_labeled_f32",
     "dcmt_complete_labeled_f32_dev", "dcmt_complete_u16_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
-    "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version",
+    "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version", "dcmt_project_points_dev",
 )
 
 
@@ -106,6 +106,7 @@ def lib() -> ctypes.CDLL:
         L.dcmt_complete_labeled_f32.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, vp, sz, sz, i, i, i, pp, i]
         L.dcmt_complete_labeled_f32_dev.argtypes = [vp, vp, vp, i, vp, i, i, i, pp, i, vp]
         L.dcmt_complete_u16_dev.argtypes = [vp, vp, ctypes.c_float, vp, i, i, i, pp, vp]
+        L.dcmt_project_points_dev.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, i, vp]
         L.dcmt_last_fill_iters.argtypes = [vp, ip, i]
         L.dcmt_last_holes_after_extend.argtypes = [vp, ip, i]
         L.dcmt_strerror.argtypes = [i]

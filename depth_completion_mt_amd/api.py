@@ -158,6 +158,28 @@ class Context:
             raise DcmtError(st, "dcmt_complete_u16_dev")
         return d_dst
 
+    def project_points_dev(self, d_points, d_offsets, T, P, rows: int, cols: int, d_sparse=None, stream: int | None = None):
+        """N2 (SL/main_sl.cpp:478-520): velodyne points -> sparse depth images on the device.  d_points: f32 CUDA tensor
+        [n][4] (x, y, z, reflectance); d_offsets: int32 CUDA tensor [batch + 1], frame f owns points
+        [offsets[f], offsets[f+1]); T 4x4, P 3x4 row-major.  Returns [batch][rows][cols] f32, 0 = no point."""
+        import torch
+        assert d_points.is_cuda and d_points.dtype == torch.float32 and d_points.is_contiguous() and d_points.shape[-1] == 4
+        assert d_offsets.is_cuda and d_offsets.dtype == torch.int32 and d_offsets.is_contiguous()
+        batch = d_offsets.numel() - 1
+        n = d_points.numel() // 4
+        if d_sparse is None:
+            d_sparse = torch.full((batch, rows, cols), float("nan"), dtype=torch.float32, device=d_points.device)
+        assert d_sparse.is_cuda and d_sparse.dtype == torch.float32 and d_sparse.is_contiguous() and tuple(d_sparse.shape) == (batch, rows, cols)
+        t = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        p = np.ascontiguousarray(P, dtype=np.float32).reshape(12)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_points.device).cuda_stream
+        st = L.lib().dcmt_project_points_dev(self._h, d_points.data_ptr(), d_offsets.data_ptr(), n, batch, t.ctypes.data, p.ctypes.data,
+                                             d_sparse.data_ptr(), rows, cols, ctypes.c_void_p(stream))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_project_points_dev")
+        return d_sparse
+
     def last_fill_iters(self, n: int):
         out = (ctypes.c_int * n)()
         st = L.lib().dcmt_last_fill_iters(self._h, out, n)

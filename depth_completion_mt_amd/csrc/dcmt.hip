@@ -603,6 +603,28 @@ int dcmt_complete_labeled_f32_dev(dcmt_ctx* ctx, const float* d_src, const int32
                      (hipStream_t)stream, false);
 }
 
+int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t* d_offsets, int n_points, int batch,
+                            const float T[16], const float P[12], float* d_sparse, int rows, int cols, void* stream)
+{
+    if (!ctx || !d_offsets || !T || !P || !d_sparse || n_points < 0 || (n_points > 0 && !d_points)) return DCMT_E_INVALID;
+    if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    ProjMats M;
+    std::memcpy(M.T, T, sizeof(float) * 12);       // the bottom row of T is never used (SL :483-485)
+    std::memcpy(M.P, P, sizeof(float) * 12);
+    int* winner = reinterpret_cast<int*>(ctx->pp[0]);   // scratch the cascade only touches after its own first kernel
+    const size_t n_px = (size_t)batch * rows * cols;
+    DCMT_HIP(ctx, hipMemsetAsync(winner, 0xFF, sizeof(int) * n_px, st));          // -1 = no point
+    if (n_points > 0)
+        hipLaunchKernelGGL(k_project_scatter, dim3((n_points + 255) / 256), dim3(256), 0, st, d_points, d_offsets, n_points, batch, M,
+                           winner, rows, cols);
+    size_t blocks = (n_px + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_project_resolve, dim3((unsigned)blocks), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
+    DCMT_HIP(ctx, hipGetLastError());
+    return DCMT_OK;
+}
+
 static int read_counters(dcmt_ctx* ctx)
 {
     DCMT_HIP(ctx, hipSetDevice(ctx->device));

@@ -132,6 +132,63 @@ void k_norm_write(const float* __restrict__ src, float* __restrict__ dst, const 
 }
 
 // ---------------------------------------------------------------------------------
+// N2: LiDAR points -> sparse depth image (SL/main_sl.cpp:478-520).  Pass 1: one thread per point; the pixel's winner
+// is the LAST point in file order = the largest point index (atomicMax on an int plane, -1 = empty).  Pass 2: one
+// thread per pixel recomputes the winning point's depth (the same deterministic arithmetic) or writes 0.
+// Every product and sum is rounded separately (__fmul_rn / __fadd_rn: no FMA contraction), sums left to right.
+// ---------------------------------------------------------------------------------
+struct ProjMats { float T[12]; float P[12]; };   // the three rows of T that are used; P
+
+__device__ __forceinline__ float dot4_rn(const float* m, float x, float y, float z)
+{
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[0], x), __fmul_rn(m[1], y)), __fmul_rn(m[2], z)), m[3]);
+}
+
+// returns false if the point is dropped; otherwise pixel (u, v) and its depth
+__device__ __forceinline__ bool project_point(const ProjMats& M, const float* p, int rows, int cols, int& u, int& v, float& depth)
+{
+    const float x = p[0], y = p[1], z = p[2];
+    const float tx = dot4_rn(M.T, x, y, z), ty = dot4_rn(M.T + 4, x, y, z), tz = dot4_rn(M.T + 8, x, y, z);
+    if (!(tz > 0.0f)) return false;                                   // SL :487
+    const float px = dot4_rn(M.P, tx, ty, tz), py = dot4_rn(M.P + 4, tx, ty, tz), pz = dot4_rn(M.P + 8, tx, ty, tz);
+    if (pz == 0.0f) return false;                                     // x/0 is +-inf or NaN: fails every bound below
+    const float uf = __fdiv_rn(px, pz), vf = __fdiv_rn(py, pz);       // SL :502-503
+    if (!(uf >= 0.0f && uf < (float)cols && vf >= 0.0f && vf < (float)rows)) return false;   // SL :506-507
+    u = (int)uf; v = (int)vf; depth = pz;
+    return true;
+}
+
+__global__ __launch_bounds__(256)
+void k_project_scatter(const float* __restrict__ pts, const int* __restrict__ offsets, int n_points, int batch,
+                       ProjMats M, int* __restrict__ winner, int rows, int cols)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    int lo = 0, hi = batch;                       // frame f with offsets[f] <= i < offsets[f+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+    int u, v; float d;
+    if (!project_point(M, pts + 4 * (size_t)i, rows, cols, u, v, d)) return;
+    atomicMax(&winner[((size_t)lo * rows + v) * cols + u], i - offsets[lo]);
+}
+
+__global__ __launch_bounds__(256)
+void k_project_resolve(const float* __restrict__ pts, const int* __restrict__ offsets, ProjMats M,
+                       const int* __restrict__ winner, float* __restrict__ sparse, int rows, int cols, int batch)
+{
+    const size_t fe = (size_t)rows * cols, n = fe * batch;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int w = winner[i];
+        float out = 0.0f;
+        if (w >= 0) {
+            const size_t f = i / fe;
+            int u, v;
+            (void)project_point(M, pts + 4 * ((size_t)offsets[f] + w), rows, cols, u, v, out);
+        }
+        sparse[i] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // init: column statistics and counters for one call
 // ---------------------------------------------------------------------------------
 __global__ void k_init(int* __restrict__ colstat, int* __restrict__ counters, int cols, int batch)

@@ -67,3 +67,32 @@ def synth_labels(rows: int = 352, cols: int = 1216, n_target: int = 1200, seed: 
     # a sprinkle of unassigned pixels (-1), as SLIC leaves some
     lab = np.where((h >> np.uint64(50)) % np.uint64(997) == 0, -1, lab)
     return lab.astype(np.int32), int(gy * gx)
+
+
+# ---- N2: synthetic velodyne sweep + KITTI-like calibration (test / bench input only) ----------------
+# velodyne frame: x forward, y left, z up; camera frame: x right, y down, z forward
+KITTI_T_VELO_TO_CAM = np.array([[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
+                                [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
+                                [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01],
+                                [0.0, 0.0, 0.0, 1.0]], dtype=np.float32)
+KITTI_P2 = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01],
+                     [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01],
+                     [0.0, 0.0, 1.0, 2.745884e-03]], dtype=np.float32)
+
+
+def synth_points(n: int, seed: int) -> np.ndarray:
+    """[n][4] f32 (x, y, z, reflectance): an HDL-64-like sweep -- azimuth over the full circle (so about three quarters
+    of the points fall behind or beside the camera, as in a real .bin), elevation -24.9..2 degrees, ranges 3..80 m
+    cut off at the ground plane 1.73 m below the sensor."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    az = g.uniform(-np.pi, np.pi, n)
+    el = np.deg2rad(g.uniform(-24.9, 2.0, n))
+    rng = g.uniform(3.0, 80.0, n)
+    ground = np.where(el < 0, 1.73 / np.maximum(np.sin(-el), 1e-6), np.inf)
+    rng = np.minimum(rng, ground)
+    pts = np.empty((n, 4), np.float32)
+    pts[:, 0] = rng * np.cos(el) * np.cos(az)
+    pts[:, 1] = rng * np.cos(el) * np.sin(az)
+    pts[:, 2] = rng * np.sin(el)
+    pts[:, 3] = g.uniform(0.0, 1.0, n)
+    return pts

@@ -168,6 +168,26 @@ int dcmt_complete_labeled_f32_dev(dcmt_ctx *ctx, const float *d_src, const int32
                                   int n_labels, float *d_dst, int rows, int cols, int batch,
                                   const dcmt_params *params, int use_superpixel, void *stream);
 
+/* ---- producer of the path's input: LiDAR points -> sparse depth image (N2) ----------- */
+
+/* What the stereo-lidar executables do between reading the velodyne .bin and calling the path
+ * (DC_stereo_lidar/main_sl.cpp:478-520 in withSuperPixels, the same loop at :320-366 in vedi_pc):
+ *     t = T * (x, y, z, 1)                 keep the point if t.z > 0                    (:480-490)
+ *     p = P * (t.x, t.y, t.z, 1);  uf = p.x / p.z,  vf = p.y / p.z                      (:499-503)
+ *     if 0 <= uf < cols and 0 <= vf < rows:  image(int(vf), int(uf)) = p.z              (:506-518)
+ * in file order, so a later point overwrites an earlier one that fell into the same pixel.
+ * d_points: device, [n_points][4] f32 = x, y, z, reflectance -- the KITTI .bin layout the reference reads (:468-472);
+ * frame f owns points [d_offsets[f], d_offsets[f+1]) (device array of batch+1 ints, d_offsets[batch] == n_points).
+ * T: 4x4, P: 3x4, both ROW-major host arrays (Eigen's default storage is column-major: pass the transposes' data()).
+ * d_sparse: [batch][rows][cols] f32, written completely (0 = no point).  All arithmetic is f32, one rounding per
+ * operation, sums left to right -- the order of the reference's hand-written transform; Eigen's evaluation order for
+ * `P * p.homogeneous()` is not pinned, so against a real build a point whose uf or vf sits
+ * within an ulp of an integer may land in the neighbouring pixel.  Stream-ordered, never synchronises; uses ctx
+ * scratch, so do not overlap it with another call on the same ctx. */
+int dcmt_project_points_dev(dcmt_ctx *ctx, const float *d_points, const int32_t *d_offsets, int n_points,
+                            int batch, const float T[16], const float P[12], float *d_sparse,
+                            int rows, int cols, void *stream);
+
 /* ---- probes ------------------------------------------------------------------------ */
 
 /* Per frame of the last call on ctx: the number of iterations the reference's while-loop

@@ -574,6 +574,39 @@ void dcmt_oracle_normalize_minmax(const float *src, float *dst, int rows, int co
     }
 }
 
+/* ---- N2: LiDAR points -> sparse depth image ------------------------------------------
+ * /root/reference/src/DC_stereo_lidar/main_sl.cpp:478-520 (withSuperPixels; vedi_pc :320-366 is the same loop):
+ * the rigid transform is written out by hand there (:483-485, f32, left to right), points with z <= 0 are dropped
+ * (:487), `P * p.homogeneous()` is an Eigen 3x4 * 4 product (:499-500), then the two divisions (:502-503), the
+ * float bounds test (:506-507), truncation to int (:511-512) and the store of the projected z (:518).  Restated with
+ * every product and sum rounded to f32 and sums taken left to right (this file is built with -ffp-contract=off).
+ * PARITY UNPINNED: Eigen is absent, its reduction order for the 4-term rows (and whether the build fuses
+ * multiply-adds) is not pinned by the reference, which has no build system. */
+static inline float dot4_rn(const float *m, float x, float y, float z)
+{
+    float a = m[0] * x;
+    float b = m[1] * y;
+    a = a + b;
+    b = m[2] * z;
+    a = a + b;
+    return a + m[3];
+}
+
+void dcmt_oracle_project_points(const float *points, int n, const float T[16], const float P[12],
+                                float *dst, int rows, int cols)
+{
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) dst[i] = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const float x = points[4 * (size_t)i], y = points[4 * (size_t)i + 1], z = points[4 * (size_t)i + 2];
+        const float tx = dot4_rn(T, x, y, z), ty = dot4_rn(T + 4, x, y, z), tz = dot4_rn(T + 8, x, y, z);
+        if (!(tz > 0.0f)) continue;
+        const float px = dot4_rn(P, tx, ty, tz), py = dot4_rn(P + 4, tx, ty, tz), pz = dot4_rn(P + 8, tx, ty, tz);
+        const float uf = px / pz, vf = py / pz;
+        if (uf >= 0.0f && uf < (float)cols && vf >= 0.0f && vf < (float)rows)
+            dst[(size_t)(int)vf * cols + (int)uf] = pz;
+    }
+}
+
 /* ---- synthetic KITTI-like sparse frame ---------------------
  * Counter-based: every pixel is a pure function of (seed,row,col), so numpy
  * (depth_completion_mt_amd/synth.py) reproduces it bit for bit. */

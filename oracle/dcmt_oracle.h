@@ -96,6 +96,11 @@ void dcmt_oracle_extend_columns(float *x, int rows, int cols);
  * (DC_stereo_lidar/main_sl.cpp:370, :523). */
 void dcmt_oracle_normalize_minmax(const float *src, float *dst, int rows, int cols, float a, float b);
 
+/* N2: LiDAR points -> sparse depth image (DC_stereo_lidar/main_sl.cpp:478-520): points [n][4] f32 (x,y,z,reflectance),
+ * T 4x4 and P 3x4 row-major; dst is overwritten completely (0 = no point); later points overwrite earlier ones. */
+void dcmt_oracle_project_points(const float *points, int n, const float T[16], const float P[12],
+                                float *dst, int rows, int cols);
+
 /* Deterministic KITTI-like synthetic sparse frame. */
 void dcmt_oracle_synth_frame(float *dst, int rows, int cols, uint64_t seed);
 

@@ -115,6 +115,29 @@ def normalize_minmax(x, lo, hi):
     return (x * F32(scale)).astype(F32) + F32(shift)
 
 
+def project_points(points, T, P, rows, cols):
+    """N2, SL/main_sl.cpp:478-520: whole-array f32 arithmetic (every numpy op rounds to f32 once, sums left to right),
+    last point in file order wins a pixel.  See dcmt_oracle.c for the line-by-line citations."""
+    pts = np.asarray(points, dtype=F32).reshape(-1, 4)
+    T = np.asarray(T, dtype=F32).reshape(4, 4)
+    P = np.asarray(P, dtype=F32).reshape(3, 4)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    dot = lambda m, a, b, c: ((m[0] * a + m[1] * b) + m[2] * c) + m[3]
+    tx, ty, tz = dot(T[0], x, y, z), dot(T[1], x, y, z), dot(T[2], x, y, z)
+    px, py, pz = dot(P[0], tx, ty, tz), dot(P[1], tx, ty, tz), dot(P[2], tx, ty, tz)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        uf, vf = px / pz, py / pz
+    ok = (tz > 0) & (uf >= 0) & (uf < F32(cols)) & (vf >= 0) & (vf < F32(rows))
+    idx = np.nonzero(ok)[0]
+    out = np.zeros((rows, cols), F32)
+    winner = np.full(rows * cols, -1, np.int64)
+    flat = vf[idx].astype(np.int64) * cols + uf[idx].astype(np.int64)
+    np.maximum.at(winner, flat, idx)
+    hit = winner >= 0
+    out.reshape(-1)[hit] = pz[winner[hit]]
+    return out
+
+
 def median5(x):
     """cv::medianBlur(x,x,5) on f32: exact median, BORDER_REPLICATE (LO :170)."""
     R, C = x.shape

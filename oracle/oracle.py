@@ -80,6 +80,8 @@ def lib(native: bool = False) -> ctypes.CDLL:
         L.dcmt_oracle_extend_columns.restype = None
         L.dcmt_oracle_normalize_minmax.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
         L.dcmt_oracle_normalize_minmax.restype = None
+        L.dcmt_oracle_project_points.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, ctypes.c_int]
+        L.dcmt_oracle_project_points.restype = None
         L.dcmt_oracle_synth_frame.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
         L.dcmt_oracle_synth_frame.restype = None
         _libs[native] = L
@@ -203,6 +205,16 @@ def extend_columns(a):
 def normalize_minmax(a, lo: float, hi: float) -> np.ndarray:
     """cv::normalize(a, dst, lo, hi, NORM_MINMAX), f32 (SL/main_sl.cpp:370, :523)."""
     return _unary("dcmt_oracle_normalize_minmax", a, ctypes.c_float(lo), ctypes.c_float(hi))
+
+
+def project_points(points, T, P, rows: int, cols: int) -> np.ndarray:
+    """SL/main_sl.cpp:478-520: points [n][4] f32, T 4x4, P 3x4 (row-major) -> sparse depth image."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    t = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+    p = np.ascontiguousarray(P, dtype=np.float32).reshape(12)
+    dst = np.empty((rows, cols), dtype=np.float32)
+    lib().dcmt_oracle_project_points(_fp(pts), pts.shape[0], _fp(t), _fp(p), _fp(dst), rows, cols)
+    return dst
 
 
 def synth_frame(rows: int, cols: int, seed: int) -> np.ndarray:

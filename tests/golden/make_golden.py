@@ -108,6 +108,23 @@ def main():
     out["norm_dense40x56_n80"] = N.normalize_minmax(x, 0, 80)
     out["norm_dense40x56_out80"] = N.img_completion(out["norm_dense40x56_n80"])
     out["norm_flat_n"] = N.normalize_minmax(np.full((8, 8), 2.0, np.float32), 5, 80)     # constant frame -> dmin everywhere
+    # N2: LiDAR points -> sparse depth image (SL/main_sl.cpp:478-520) on a 48x64 image: a synthetic sweep through a
+    # camera with an 80-pixel focal length, plus hand-placed points for the rules (file order wins a pixel, z <= 0 is
+    # dropped, the bounds are tested on the float coordinates before truncation)
+    T = synth.KITTI_T_VELO_TO_CAM.copy()
+    P = np.array([[80.0, 0.0, 32.0, 4.0], [0.0, 80.0, 20.0, 0.02], [0.0, 0.0, 1.0, 0.003]], np.float32)
+    pts = synth.synth_points(4000, 41)
+    extra = np.array([[10.0, 0.0, 0.0, 0.5], [20.0, 0.0, 0.0, 0.5], [15.0, 0.0, 0.0, 0.5],      # same pixel three times: the last (15 m) stays
+                      [-5.0, 0.0, 0.0, 0.5],                                                   # behind the camera
+                      [0.2717806, 0.0, 0.0, 0.5],                                              # t.z within rounding of 0
+                      [10.0, 4.5, 0.0, 0.5], [10.0, -3.6, 0.0, 0.5],                           # near the left / right image edge
+                      [10.0, 0.0, 2.6, 0.5], [10.0, 0.0, -3.3, 0.5]], np.float32)              # near the top / bottom edge
+    pts = np.concatenate([pts[:2000], extra, pts[2000:], extra[:3][::-1]])
+    out["proj_points"] = pts
+    out["proj_T"] = T
+    out["proj_P"] = P
+    out["proj_sparse48x64"] = N.project_points(pts, T, P, 48, 64)
+    out["proj_chain48x64"] = N.img_completion(N.normalize_minmax(out["proj_sparse48x64"], 0, 100))   # SL :370-386 end to end
     np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **out)
 
     # full-size frames: checksums only (inputs come from the generator)

@@ -409,3 +409,39 @@ def test_n1_normalize_fused_in_front_of_the_path(ctx, golden, golden_meta, O):
     with pytest.raises(api.DcmtError) as e:       # stage 1 only exists with the flag
         ctx.complete(x, api.make_params(stop_after=L.STAGE_NORMALIZE))
     assert e.value.status == L.E_INVALID
+
+
+def test_n2_lidar_projection_to_sparse_image(ctx, golden, O):
+    """dcmt_project_points_dev = the loop that builds the path's input in the stereo-lidar executables
+    (SL/main_sl.cpp:478-520): bit-exact against the goldens and the oracle, including the file-order rule for points
+    that share a pixel, ragged batches and an empty sweep; then the whole :370-386 sequence on the device."""
+    import torch
+    pts, T, P = golden["proj_points"], golden["proj_T"], golden["proj_P"]
+    off = torch.tensor([0, len(pts)], dtype=torch.int32, device="cuda")
+    got = ctx.project_points_dev(torch.from_numpy(pts).cuda(), off, T, P, 48, 64)
+    torch.cuda.synchronize()
+    assert_bit_equal(got.cpu().numpy()[0], golden["proj_sparse48x64"], "projection 48x64")
+    # ragged batch at config 4's size: sweeps of different lengths, one of them empty, many collisions
+    sweeps = [synth.synth_points(n, 50 + i) for i, n in enumerate((120000, 0, 60000, 250000))]
+    sweeps[2][:, :3] = sweeps[2][0, :3]                           # 60000 points marching through a few dozen pixels:
+    sweeps[2][:, 0] += np.linspace(0, 5, len(sweeps[2]), dtype=np.float32)   # hundreds of writers per pixel, the last in file order stays
+    allp = np.concatenate(sweeps)
+    offs = np.cumsum([0] + [len(s) for s in sweeps]).astype(np.int32)
+    T4, P4 = synth.KITTI_T_VELO_TO_CAM, synth.KITTI_P2
+    with api.Context(0, 375, 1242, 4) as c:
+        d_sparse = c.project_points_dev(torch.from_numpy(allp).cuda(), torch.from_numpy(offs).cuda(), T4, P4, 375, 1242)
+        torch.cuda.synchronize()
+        sp = d_sparse.cpu().numpy()
+        for f, s in enumerate(sweeps):
+            assert_bit_equal(sp[f], O.project_points(s, T4, P4, 375, 1242), f"sweep {f}")
+        assert not sp[1].any() and 1 <= (sp[2] > 0).sum() < 200
+        # project -> normalize(0, 100) -> img_completion, all on the device (main_sl.cpp:320-386)
+        dense = c.complete_dev(d_sparse, params=api.make_params(normalize=(0, 100), force_fused=True))
+        torch.cuda.synchronize()
+        dn = dense.cpu().numpy()
+        for f in (0, 3):
+            assert_bit_equal(dn[f], O.img_completion(O.normalize_minmax(sp[f], 0, 100)), f"chain on sweep {f}")
+        assert not dn[1].any()                                       # empty sweep -> empty image -> all zero (K1)
+    with pytest.raises(api.DcmtError) as e:                          # image larger than the context was created for
+        ctx.project_points_dev(torch.from_numpy(pts).cuda(), off, T, P, 4000, 64)
+    assert e.value.status == L.E_INVALID

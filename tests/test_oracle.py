@@ -217,3 +217,24 @@ def test_n1_normalize_goldens_and_known_answers(golden):
     assert (golden["norm_flat_n"] == 5.0).all()                 # smax - smin <= DBL_EPSILON: scale 0, everything = dmin
     # scaling by a power of two commutes exactly with the normalisation
     assert_bit_equal(O.normalize_minmax(x * np.float32(4.0), 0, 100), n100, "power-of-two input scale")
+
+
+def test_n2_projection_goldens_and_rules(golden):
+    """N2 (SL/main_sl.cpp:478-520, LiDAR points -> sparse depth image): C oracle == numpy restatement's goldens, and
+    the rules of the reference loop one by one."""
+    from oracle import oracle as O
+    from depth_completion_mt_amd import synth
+    pts, T, P = golden["proj_points"], golden["proj_T"], golden["proj_P"]
+    got = O.project_points(pts, T, P, 48, 64)
+    assert_bit_equal(got, golden["proj_sparse48x64"], "projection 48x64")
+    assert_bit_equal(O.img_completion(O.normalize_minmax(got, 0, 100)), golden["proj_chain48x64"], "project -> normalize -> complete")
+    one = lambda rows: O.project_points(np.asarray(rows, np.float32), T, P, 48, 64)
+    a = one([[10, 0, 0, 0], [20, 0, 0, 0]])
+    b = one([[20, 0, 0, 0], [10, 0, 0, 0]])
+    assert (a > 0).sum() == 1 and (b > 0).sum() == 1 and a.max() > 19 and b.max() < 11    # file order: the later point stays
+    assert not one([[-5, 0, 0, 0]]).any()                                                    # behind the camera (t.z <= 0)
+    assert not one([[10, 40, 0, 0]]).any() and not one([[10, 0, 30, 0]]).any()               # outside the image
+    assert not O.project_points(np.zeros((0, 4), np.float32), T, P, 48, 64).any()             # empty sweep -> empty image
+    # full-size sweep: KITTI-like density, and depth = z in the camera frame (third row of P is ~[0 0 1 0])
+    full = O.project_points(synth.synth_points(120000, 0), synth.KITTI_T_VELO_TO_CAM, synth.KITTI_P2, 375, 1242)
+    assert 0.02 < (full > 0).mean() < 0.06 and full.max() < 81.0
