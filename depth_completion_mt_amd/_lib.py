@@ -27,6 +27,7 @@ EXPORTS = (
     "dcmt_k0_diamond", "dcmt_complete_f32", "dcmt_complete_f32_dev", "dcmt_complete_labeled_f32",
     "dcmt_complete_labeled_f32_dev", "dcmt_complete_u16_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
     "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version", "dcmt_project_points_dev",
+    "dcmt_slic_num_centers", "dcmt_slic_labels_dev",
 )
 
 
@@ -107,6 +108,8 @@ def lib() -> ctypes.CDLL:
         L.dcmt_complete_labeled_f32_dev.argtypes = [vp, vp, vp, i, vp, i, i, i, pp, i, vp]
         L.dcmt_complete_u16_dev.argtypes = [vp, vp, ctypes.c_float, vp, i, i, i, pp, vp]
         L.dcmt_project_points_dev.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, i, vp]
+        L.dcmt_slic_num_centers.argtypes = [i, i, i]
+        L.dcmt_slic_labels_dev.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
         L.dcmt_last_fill_iters.argtypes = [vp, ip, i]
         L.dcmt_last_holes_after_extend.argtypes = [vp, ip, i]
         L.dcmt_strerror.argtypes = [i]

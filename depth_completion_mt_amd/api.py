@@ -180,6 +180,26 @@ class Context:
             raise DcmtError(st, "dcmt_project_points_dev")
         return d_sparse
 
+    def slic_labels_dev(self, d_lab, step: int, nc: int, d_labels=None, return_centers: bool = False, stream: int | None = None):
+        """N3, Slic::generate_superpixels (LC/slic.cpp:101-182) on the device.  d_lab: uint8 CUDA tensor [batch][rows][cols][3]
+        (or [rows][cols][3]).  Returns (labels int32 [batch][rows][cols], n_centers[, centers float64 [batch][n][5]])."""
+        import torch
+        assert d_lab.is_cuda and d_lab.dtype == torch.uint8 and d_lab.is_contiguous() and d_lab.shape[-1] == 3
+        shp = d_lab.shape if d_lab.dim() == 4 else (1,) + tuple(d_lab.shape)
+        b, r, c = shp[0], shp[1], shp[2]
+        n = L.lib().dcmt_slic_num_centers(r, c, int(step))
+        if d_labels is None:
+            d_labels = torch.full((b, r, c), -7, dtype=torch.int32, device=d_lab.device)
+        assert d_labels.is_cuda and d_labels.dtype == torch.int32 and d_labels.is_contiguous() and tuple(d_labels.shape) == (b, r, c)
+        d_cent = torch.empty((b, max(n, 1), 5), dtype=torch.float64, device=d_lab.device) if return_centers else None
+        if stream is None:
+            stream = torch.cuda.current_stream(d_lab.device).cuda_stream
+        st = L.lib().dcmt_slic_labels_dev(self._h, d_lab.data_ptr(), r, c, b, int(step), int(nc), d_labels.data_ptr(),
+                                          d_cent.data_ptr() if return_centers else None, ctypes.c_void_p(stream))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_slic_labels_dev")
+        return (d_labels, n, d_cent[:, :n]) if return_centers else (d_labels, n)
+
     def last_fill_iters(self, n: int):
         out = (ctypes.c_int * n)()
         st = L.lib().dcmt_last_fill_iters(self._h, out, n)

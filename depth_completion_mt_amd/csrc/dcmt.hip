@@ -16,6 +16,7 @@
 #include "dcmt.h"
 #include "dcmt_kernels_v1.h"
 #include "dcmt_kernels_fused.h"
+#include "dcmt_kernels_slic.h"
 
 using namespace dcmt;
 
@@ -50,6 +51,12 @@ struct dcmt_ctx {
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
+    // N3 (SLIC) scratch, allocated by the first dcmt_slic_labels_dev call
+    unsigned long long* slic_dist = nullptr;    // [max_batch][rows][cols] f64 bits
+    int* slic_new = nullptr;                    // [max_batch][rows][cols]
+    double* slic_centers[2] = {nullptr, nullptr};
+    unsigned long long* slic_sums = nullptr;
+    size_t slic_center_cap = 0;                 // centres per frame the two buffers above hold
     int label_pairs = -1;             // LC fast path: one wave per label pair (1), per label (0), by label size (-1); env DCMT_LABEL_PAIRS
     int min_fused_batch = 12;         // smaller batches use the staged kernels (measured crossover: tools/batch_sweep.py); env DCMT_MIN_FUSED_BATCH
 };
@@ -558,6 +565,8 @@ void dcmt_destroy(dcmt_ctx* ctx)
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
     (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);
+    (void)hipFree(ctx->slic_dist); (void)hipFree(ctx->slic_new); (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]);
+    (void)hipFree(ctx->slic_sums);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     delete ctx;
 }
@@ -622,6 +631,60 @@ int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t*
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_project_resolve, dim3((unsigned)blocks), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
     DCMT_HIP(ctx, hipGetLastError());
+    return DCMT_OK;
+}
+
+int dcmt_slic_num_centers(int rows, int cols, int step)
+{
+    if (rows < 1 || cols < 1 || step < 1) return 0;
+    int nx = 0, ny = 0;
+    for (int i = step; i < cols - step / 2; i += step) ++nx;     // slic.cpp:33-34
+    for (int j = step; j < rows - step / 2; j += step) ++ny;
+    return nx * ny;
+}
+
+int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols, int batch, int step, int nc,
+                         int32_t* d_labels, double* d_centers, void* stream)
+{
+    if (!ctx || !d_lab || !d_labels) return DCMT_E_INVALID;
+    if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
+    if (step < 6 || nc < 1) return DCMT_E_INVALID;
+    const int n = dcmt_slic_num_centers(rows, cols, step);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t px = (size_t)batch * rows * cols;
+    if (n == 0) { DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st)); return DCMT_OK; }
+    DCMT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t max_px = ctx->frame_elems * (size_t)ctx->max_batch;
+    if (!ctx->slic_dist) DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_dist, sizeof(unsigned long long) * max_px));
+    if (!ctx->slic_new) DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_new, sizeof(int) * max_px));
+    if ((size_t)n > ctx->slic_center_cap) {
+        (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]); (void)hipFree(ctx->slic_sums);
+        ctx->slic_centers[0] = ctx->slic_centers[1] = nullptr; ctx->slic_sums = nullptr; ctx->slic_center_cap = 0;
+        const size_t cn = (size_t)n * ctx->max_batch;
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_centers[0], sizeof(double) * 5 * cn));
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_centers[1], sizeof(double) * 5 * cn));
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_sums, sizeof(unsigned long long) * 6 * cn));
+        ctx->slic_center_cap = (size_t)n;
+    }
+    DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st));                    // clusters = -1 (slic.cpp:24)
+    hipLaunchKernelGGL(k_slic_init, dim3((n + 63) / 64, batch), dim3(64), 0, st, d_lab, ctx->slic_centers[0], rows, cols, step, n);
+    size_t mblocks = (px + 255) / 256;
+    if (mblocks > 16384) mblocks = 16384;
+    for (int it = 0; it < 10; ++it) {                                                           // NR_ITERATIONS (slic.h:20)
+        double* cur = ctx->slic_centers[it & 1];
+        double* nxt = ctx->slic_centers[(it + 1) & 1];
+        DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_dist, 0x7f, sizeof(unsigned long long) * px, st));     // "FLT_MAX": above every distance
+        DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_new, 0x7f, sizeof(int) * px, st));
+        DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_sums, 0, sizeof(unsigned long long) * 6 * (size_t)n * batch, st));
+        hipLaunchKernelGGL((k_slic_dist<false>), dim3(n, batch), dim3(256), 0, st, d_lab, cur, ctx->slic_dist, ctx->slic_new, rows, cols, step, nc, n);
+        hipLaunchKernelGGL((k_slic_dist<true>), dim3(n, batch), dim3(256), 0, st, d_lab, cur, ctx->slic_dist, ctx->slic_new, rows, cols, step, nc, n);
+        hipLaunchKernelGGL(k_slic_accum, dim3(n, batch), dim3(256), 0, st, d_lab, cur, ctx->slic_new, ctx->slic_sums, rows, cols, step, n);
+        hipLaunchKernelGGL(k_slic_merge, dim3((unsigned)mblocks), dim3(256), 0, st, d_lab, ctx->slic_new, d_labels, ctx->slic_sums, rows, cols, n, batch);
+        hipLaunchKernelGGL(k_slic_norm, dim3((n * batch + 255) / 256), dim3(256), 0, st, ctx->slic_sums, nxt, n * batch);
+        DCMT_HIP(ctx, hipGetLastError());
+    }
+    if (d_centers)       // ten iterations: the final centres are back in buffer 0
+        DCMT_HIP(ctx, hipMemcpyAsync(d_centers, ctx->slic_centers[0], sizeof(double) * 5 * (size_t)n * batch, hipMemcpyDeviceToDevice, st));
     return DCMT_OK;
 }
 

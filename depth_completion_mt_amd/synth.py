@@ -96,3 +96,23 @@ def synth_points(n: int, seed: int) -> np.ndarray:
     pts[:, 2] = rng * np.sin(el)
     pts[:, 3] = g.uniform(0.0, 1.0, n)
     return pts
+
+
+def synth_lab(rows: int, cols: int, seed: int) -> np.ndarray:
+    """[rows][cols][3] uint8: a stand-in for cv::cvtColor(BGR2Lab) output -- smooth colour regions (a random coarse
+    grid, bilinearly interpolated) with edges (a few rectangles of constant colour) and a little noise."""
+    g = np.random.Generator(np.random.PCG64(seed + 7919))
+    gy, gx = rows // 40 + 2, cols // 40 + 2
+    coarse = g.uniform(30, 220, (gy, gx, 3))
+    ys = np.linspace(0, gy - 1.001, rows)
+    xs = np.linspace(0, gx - 1.001, cols)
+    y0, x0 = ys.astype(int), xs.astype(int)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    img = (coarse[y0][:, x0] * (1 - fy) * (1 - fx) + coarse[y0][:, x0 + 1] * (1 - fy) * fx
+           + coarse[y0 + 1][:, x0] * fy * (1 - fx) + coarse[y0 + 1][:, x0 + 1] * fy * fx)
+    for _ in range(12):
+        r0, c0 = int(g.integers(0, rows - 8)), int(g.integers(0, cols - 8))
+        r1, c1 = min(rows, r0 + int(g.integers(8, rows // 3 + 9))), min(cols, c0 + int(g.integers(8, cols // 4 + 9)))
+        img[r0:r1, c0:c1] = g.uniform(20, 235, 3)
+    img += g.normal(0, 2.0, img.shape)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))

@@ -188,6 +188,23 @@ int dcmt_project_points_dev(dcmt_ctx *ctx, const float *d_points, const int32_t 
                             int batch, const float T[16], const float P[12], float *d_sparse,
                             int rows, int cols, void *stream);
 
+/* ---- producer of the label plane: SLIC superpixels (N3) -------------------------------- */
+
+/* Slic::generate_superpixels (DC_lidar_camera/slic.cpp:101-182; called at main_lc.cpp:200 with 1200 superpixels and
+ * DC_stereo_lidar/main_sl.cpp:450 with 100) on the device: the grid of centres moved to their 3x3 gradient minimum
+ * (init_data :19-57), then NR_ITERATIONS = 10 rounds of "every pixel of a centre's [c - step, c + step) window takes the
+ * centre with the smallest distance (compute_dist :59-68, f64), the lowest index on ties" and "every centre becomes the
+ * mean of its pixels".  d_lab: [batch][rows][cols][3] uint8 -- the image the reference passes (its cv::cvtColor(BGR2Lab)
+ * output); step, nc: the reference's int arguments (step = (int)sqrt(w*h / n_superpixels), nc = 50 / 40).
+ * d_labels: [batch][rows][cols] int32, row-major (the reference's clusters[col][row]), -1 = never reached: exactly what
+ * dcmt_complete_labeled_f32_dev takes, with n_labels = dcmt_slic_num_centers(rows, cols, step).
+ * d_centers (may be NULL): [batch][n][5] f64 = L, a, b, x, y after the last iteration.
+ * The first call allocates SLIC scratch (12 B per pixel of max_batch frames); later calls never allocate.
+ * Requires step >= 6 (below that the reference's gradient probe reads outside the image) and nc >= 1. */
+int dcmt_slic_num_centers(int rows, int cols, int step);
+int dcmt_slic_labels_dev(dcmt_ctx *ctx, const uint8_t *d_lab, int rows, int cols, int batch, int step, int nc,
+                         int32_t *d_labels, double *d_centers, void *stream);
+
 /* ---- probes ------------------------------------------------------------------------ */
 
 /* Per frame of the last call on ctx: the number of iterations the reference's while-loop

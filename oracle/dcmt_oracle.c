@@ -607,6 +607,98 @@ void dcmt_oracle_project_points(const float *points, int n, const float T[16], c
     }
 }
 
+/* ---- N3: SLIC superpixels ---------------------------------------------------------------
+ * /root/reference/src/DC_lidar_camera/slic.cpp, restated line by line in the same loop orders:
+ *   init_data :19-57          labels -1, centres on a grid (x outer, y inner: `i = step; i < cols - step/2; i += step`),
+ *                             each moved to the lowest-gradient pixel of its 3x3 neighbourhood (find_local_minimum
+ *                             :71-98, first minimum in x-outer / y-inner order, the comparison on
+ *                             sqrt(pow(d1,2)) + sqrt(pow(d2,2)) = |d1| + |d2|);
+ *   generate_superpixels :101-182, NR_ITERATIONS = 10 (slic.h:20):
+ *     distances = FLT_MAX; for every centre in index order, every pixel of its [c - step, c + step) window
+ *     (`int k = centers[j][3] - step; k < centers[j][3] + step`: truncating conversion, double comparison) takes the
+ *     centre if compute_dist is strictly smaller -- ties therefore stay with the lower centre index;
+ *     compute_dist :59-68 in double: dc, ds Euclidean, sqrt((dc/nc)^2 + (ds/ns)^2), ns = step;
+ *     then every centre becomes the mean of its pixels (:150-172; sums of integers, exact in double).
+ *   A pixel no window reaches keeps the label it had (the reference resets the distances, not the clusters).
+ * pow(x, 2) is restated as x * x (what it evaluates to); everything else is +, -, /, sqrt on doubles, each correctly
+ * rounded, no contraction (-ffp-contract=off).  A centre that loses all its pixels becomes NaN in the reference and
+ * its window loop never runs again (`k < NaN` is false); here it is flagged dead to the same effect.
+ * create_connectivity (:186-259) only fills a local array nothing reads, so it is not part of the path.
+ * PARITY UNPINNED, as the rest of this file (never diffed against an executing build of the reference). */
+static double slic_dist(const double *c, int x, int y, const uint8_t *px, int nc, int ns)
+{
+    const double d0 = c[0] - (double)px[0], d1 = c[1] - (double)px[1], d2 = c[2] - (double)px[2];
+    const double dc = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const double e0 = c[3] - (double)x, e1 = c[4] - (double)y;
+    const double ds = sqrt(e0 * e0 + e1 * e1);
+    const double a = dc / (double)nc, b = ds / (double)ns;
+    return sqrt(a * a + b * b);
+}
+
+int dcmt_oracle_slic(const uint8_t *lab, int rows, int cols, int step, int nc, int32_t *labels,
+                     double *centers_out, int max_centers)
+{
+    if (step < 6 || nc < 1) return -1;          /* the 3x3 gradient probe of init_data would read outside the image */
+    const int ns = step;
+    int n = 0;
+    for (int i = step; i < cols - step / 2; i += step)
+        for (int j = step; j < rows - step / 2; j += step) ++n;
+    if (n > max_centers) return -1;
+    double *C = (double *)malloc(sizeof(double) * 5 * (size_t)(n > 0 ? n : 1));
+    double *dist = (double *)malloc(sizeof(double) * (size_t)rows * cols);
+    long long *sum = (long long *)malloc(sizeof(long long) * 6 * (size_t)(n > 0 ? n : 1));
+    char *dead = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    if (!C || !dist || !sum || !dead) { free(C); free(dist); free(sum); free(dead); return -1; }
+    for (size_t p = 0; p < (size_t)rows * cols; ++p) labels[p] = -1;
+#define LAB(y, x) (lab + 3 * ((size_t)(y) * cols + (x)))
+    int c = 0;
+    for (int i = step; i < cols - step / 2; i += step)
+        for (int j = step; j < rows - step / 2; j += step) {
+            double min_grad = FLT_MAX;
+            int mx = i, my = j;
+            for (int ii = i - 1; ii < i + 2; ++ii)
+                for (int jj = j - 1; jj < j + 2; ++jj) {
+                    const double i1 = LAB(jj + 1, ii)[0], i2 = LAB(jj, ii + 1)[0], i3 = LAB(jj, ii)[0];
+                    if (fabs(i1 - i3) + fabs(i2 - i3) < min_grad) { min_grad = fabs(i1 - i3) + fabs(i2 - i3); mx = ii; my = jj; }
+                }
+            C[5 * c] = LAB(my, mx)[0]; C[5 * c + 1] = LAB(my, mx)[1]; C[5 * c + 2] = LAB(my, mx)[2];
+            C[5 * c + 3] = mx; C[5 * c + 4] = my;
+            ++c;
+        }
+    for (int it = 0; it < 10; ++it) {
+        for (size_t p = 0; p < (size_t)rows * cols; ++p) dist[p] = FLT_MAX;
+        for (int j = 0; j < n; ++j) {
+            if (dead[j]) continue;
+            const double cx = C[5 * j + 3], cy = C[5 * j + 4];
+            for (int k = (int)(cx - step); k < cx + step; ++k)
+                for (int l = (int)(cy - step); l < cy + step; ++l)
+                    if (k >= 0 && k < cols && l >= 0 && l < rows) {
+                        const double d = slic_dist(C + 5 * j, k, l, LAB(l, k), nc, ns);
+                        if (d < dist[(size_t)l * cols + k]) { dist[(size_t)l * cols + k] = d; labels[(size_t)l * cols + k] = j; }
+                    }
+        }
+        for (int j = 0; j < 6 * n; ++j) sum[j] = 0;
+        for (int x = 0; x < cols; ++x)
+            for (int y = 0; y < rows; ++y) {
+                const int id = labels[(size_t)y * cols + x];
+                if (id != -1) {
+                    const uint8_t *px = LAB(y, x);
+                    sum[6 * id] += px[0]; sum[6 * id + 1] += px[1]; sum[6 * id + 2] += px[2];
+                    sum[6 * id + 3] += x; sum[6 * id + 4] += y; sum[6 * id + 5] += 1;
+                }
+            }
+        for (int j = 0; j < n; ++j) {
+            dead[j] = sum[6 * j + 5] == 0;      /* 0/0: NaN in the reference until pixels carry this label again */
+            if (dead[j]) { for (int q = 0; q < 5; ++q) C[5 * j + q] = NAN; continue; }
+            for (int q = 0; q < 5; ++q) C[5 * j + q] = (double)sum[6 * j + q] / (double)sum[6 * j + 5];
+        }
+    }
+#undef LAB
+    if (centers_out) memcpy(centers_out, C, sizeof(double) * 5 * (size_t)n);
+    free(C); free(dist); free(sum); free(dead);
+    return n;
+}
+
 /* ---- synthetic KITTI-like sparse frame ---------------------
  * Counter-based: every pixel is a pure function of (seed,row,col), so numpy
  * (depth_completion_mt_amd/synth.py) reproduces it bit for bit. */

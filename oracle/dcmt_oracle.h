@@ -101,6 +101,16 @@ void dcmt_oracle_normalize_minmax(const float *src, float *dst, int rows, int co
 void dcmt_oracle_project_points(const float *points, int n, const float T[16], const float P[12],
                                 float *dst, int rows, int cols);
 
+/* N3: Slic::generate_superpixels (DC_lidar_camera/slic.cpp:101-182 with init_data :19-57, compute_dist :59-68,
+ * find_local_minimum :71-98) -- the producer of the label plane of interpolate_with_superpixels.
+ * lab: the 8-bit 3-channel image the caller hands over ([rows][cols][3]; the reference passes cv::cvtColor(BGR2Lab)).
+ * step, nc as the reference's int parameters (the callers' double step is truncated at the call, main_lc.cpp:200).
+ * labels: int32 [rows][cols] row-major (the reference's clusters[col][row]); -1 = never assigned.
+ * centers (may be NULL): [n][5] doubles = L, a, b, x, y after the last iteration.  Returns the number of centres
+ * (= slic.centers.size(), the n_labels of the label-masked stage), or -1 if max_centers is too small / step < 6. */
+int dcmt_oracle_slic(const uint8_t *lab, int rows, int cols, int step, int nc, int32_t *labels,
+                     double *centers, int max_centers);
+
 /* Deterministic KITTI-like synthetic sparse frame. */
 void dcmt_oracle_synth_frame(float *dst, int rows, int cols, uint64_t seed);
 

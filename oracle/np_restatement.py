@@ -138,6 +138,64 @@ def project_points(points, T, P, rows, cols):
     return out
 
 
+def slic(lab, step, nc, iterations=10):
+    """N3, Slic::generate_superpixels (LC/slic.cpp:101-182): one numpy window operation per centre instead of the
+    reference's scalar loops; float64 throughout.  Returns (labels int32 [rows][cols], n_centers, centers [n][5])."""
+    img = np.asarray(lab, dtype=np.uint8)
+    rows, cols = img.shape[:2]
+    f = img.astype(np.float64)
+    ns = step
+    cents = []
+    for i in range(step, cols - step // 2, step):          # init_data :33-56: x outer, y inner
+        for j in range(step, rows - step // 2, step):
+            best, loc = np.float64(np.finfo(np.float32).max), (i, j)
+            for ii in range(i - 1, i + 2):                 # find_local_minimum :71-98
+                for jj in range(j - 1, j + 2):
+                    gsum = abs(f[jj + 1, ii, 0] - f[jj, ii, 0]) + abs(f[jj, ii + 1, 0] - f[jj, ii, 0])
+                    if gsum < best:
+                        best, loc = gsum, (ii, jj)
+            cents.append([f[loc[1], loc[0], 0], f[loc[1], loc[0], 1], f[loc[1], loc[0], 2], loc[0], loc[1]])
+    C = np.array(cents, dtype=np.float64).reshape(-1, 5)
+    n = len(C)
+    labels = np.full((rows, cols), -1, np.int32)
+    for _ in range(iterations):
+        dist = np.full((rows, cols), np.float64(np.finfo(np.float32).max))
+        for j in range(n):
+            cx, cy = C[j, 3], C[j, 4]
+            if np.isnan(cx):
+                continue
+            k0, l0 = int(cx - step), int(cy - step)        # truncation, as `int k = centers[j][3] - step`
+            ks = np.arange(k0, int(np.ceil(cx + step)) + 1)
+            ls = np.arange(l0, int(np.ceil(cy + step)) + 1)
+            ks = ks[(ks < cx + step) & (ks >= 0) & (ks < cols)]
+            ls = ls[(ls < cy + step) & (ls >= 0) & (ls < rows)]
+            if len(ks) == 0 or len(ls) == 0:
+                continue
+            win = f[ls[0]:ls[-1] + 1, ks[0]:ks[-1] + 1]
+            d0, d1, d2 = C[j, 0] - win[..., 0], C[j, 1] - win[..., 1], C[j, 2] - win[..., 2]
+            dc = np.sqrt(d0 * d0 + d1 * d1 + d2 * d2)
+            e0 = (C[j, 3] - ks.astype(np.float64))[None, :]
+            e1 = (C[j, 4] - ls.astype(np.float64))[:, None]
+            ds = np.sqrt(e0 * e0 + e1 * e1)
+            a, b = dc / np.float64(nc), ds / np.float64(ns)
+            d = np.sqrt(a * a + b * b)
+            sub_d = dist[ls[0]:ls[-1] + 1, ks[0]:ks[-1] + 1]
+            sub_l = labels[ls[0]:ls[-1] + 1, ks[0]:ks[-1] + 1]
+            better = d < sub_d                              # strict: ties stay with the lower centre index
+            sub_d[better] = d[better]
+            sub_l[better] = j
+        yy, xx = np.indices((rows, cols))
+        ok = labels >= 0
+        idx = labels[ok]
+        cnt = np.bincount(idx, minlength=n).astype(np.float64)
+        newC = np.empty_like(C)
+        for q, vals in enumerate((f[..., 0][ok], f[..., 1][ok], f[..., 2][ok], xx[ok].astype(np.float64), yy[ok].astype(np.float64))):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                newC[:, q] = np.bincount(idx, weights=vals, minlength=n) / cnt      # integer-valued sums: exact in float64
+        C = newC
+    return labels, n, C
+
+
 def median5(x):
     """cv::medianBlur(x,x,5) on f32: exact median, BORDER_REPLICATE (LO :170)."""
     R, C = x.shape

@@ -82,6 +82,9 @@ def lib(native: bool = False) -> ctypes.CDLL:
         L.dcmt_oracle_normalize_minmax.restype = None
         L.dcmt_oracle_project_points.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, ctypes.c_int]
         L.dcmt_oracle_project_points.restype = None
+        L.dcmt_oracle_slic.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p,
+                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        L.dcmt_oracle_slic.restype = ctypes.c_int
         L.dcmt_oracle_synth_frame.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
         L.dcmt_oracle_synth_frame.restype = None
         _libs[native] = L
@@ -215,6 +218,23 @@ def project_points(points, T, P, rows: int, cols: int) -> np.ndarray:
     dst = np.empty((rows, cols), dtype=np.float32)
     lib().dcmt_oracle_project_points(_fp(pts), pts.shape[0], _fp(t), _fp(p), _fp(dst), rows, cols)
     return dst
+
+
+def slic(lab_image, step: int, nc: int, return_centers: bool = False):
+    """Slic::generate_superpixels (LC/slic.cpp:101-182) on an 8-bit 3-channel image [rows][cols][3]:
+    returns (labels int32 [rows][cols], n_centers[, centers float64 [n][5]])."""
+    img = np.ascontiguousarray(lab_image, dtype=np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3
+    rows, cols = img.shape[:2]
+    labels = np.empty((rows, cols), dtype=np.int32)
+    cap = max(1, (cols // max(step, 1) + 1) * (rows // max(step, 1) + 1))
+    centers = np.empty((cap, 5), dtype=np.float64)
+    n = lib().dcmt_oracle_slic(img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rows, cols, int(step), int(nc),
+                               labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                               centers.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
+    if n < 0:
+        raise ValueError("dcmt_oracle_slic: step < 6 or nc < 1")
+    return (labels, n, centers[:n].copy()) if return_centers else (labels, n)
 
 
 def synth_frame(rows: int, cols: int, seed: int) -> np.ndarray:

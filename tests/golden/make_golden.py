@@ -125,6 +125,16 @@ def main():
     out["proj_P"] = P
     out["proj_sparse48x64"] = N.project_points(pts, T, P, 48, 64)
     out["proj_chain48x64"] = N.img_completion(N.normalize_minmax(out["proj_sparse48x64"], 0, 100))   # SL :370-386 end to end
+    # N3: SLIC labels (LC/slic.cpp:101-182) on a 96x160 synthetic 8-bit image, step 12, nc 40; and the chain the
+    # lidar-camera executable runs behind it (main_lc.cpp:200, :220): labels -> interpolate_with_superpixels
+    img = synth.synth_lab(96, 160, 5)
+    slab, sn, scent = N.slic(img, 12, 40)
+    out["slic_lab96x160"] = img
+    out["slic_labels96x160"] = slab
+    out["slic_centers96x160"] = scent
+    meta["slic96x160_n"] = int(sn)
+    x = synth.synth_frame(96, 160, 5)
+    out["slic_chain96x160"] = N.interpolate_with_superpixels(x, slab, sn)
     np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **out)
 
     # full-size frames: checksums only (inputs come from the generator)

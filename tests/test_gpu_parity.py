@@ -445,3 +445,41 @@ def test_n2_lidar_projection_to_sparse_image(ctx, golden, O):
     with pytest.raises(api.DcmtError) as e:                          # image larger than the context was created for
         ctx.project_points_dev(torch.from_numpy(pts).cuda(), off, T, P, 4000, 64)
     assert e.value.status == L.E_INVALID
+
+
+def test_n3_slic_labels_on_the_device(golden, golden_meta, O):
+    """dcmt_slic_labels_dev = Slic::generate_superpixels (LC/slic.cpp:101-182): labels equal to the oracle's pixel for
+    pixel and the f64 centres bit for bit -- on the golden (which has a centre that dies), at both executables'
+    settings (1200 superpixels / nc 50 at 352x1216, 100 / nc 40 at 375x1242), batched with different images; then
+    SLIC -> interpolate_with_superpixels on the device, the two steps main_lc.cpp:200 and :220 chain."""
+    import torch
+    img = golden["slic_lab96x160"]
+    with api.Context(0, 96, 160, 1) as c:
+        lab, n, cent = c.slic_labels_dev(torch.from_numpy(img).cuda(), 12, 40, return_centers=True)
+        torch.cuda.synchronize()
+        assert n == golden_meta["slic96x160_n"]
+        assert np.array_equal(lab.cpu().numpy()[0], golden["slic_labels96x160"])
+        got, want = cent.cpu().numpy()[0], golden["slic_centers96x160"]
+        dead = np.isnan(want[:, 3])
+        assert np.array_equal(np.isnan(got[:, 3]), dead)
+        assert np.array_equal(got[~dead].view(np.uint64), want[~dead].view(np.uint64))
+        x = synth.synth_frame(96, 160, 5)
+        dense = c.complete_dev(torch.from_numpy(x).cuda()[None], d_labels=lab, n_labels=n, params=api.make_params(force_fused=True))
+        torch.cuda.synchronize()
+        assert_bit_equal(dense.cpu().numpy()[0], golden["slic_chain96x160"], "SLIC -> interpolate_with_superpixels")
+    for rows, cols, nsp, nc in ((352, 1216, 1200, 50), (375, 1242, 100, 40)):
+        step = int(np.sqrt(rows * cols / nsp))                        # the callers' double step, truncated at the call
+        imgs = np.ascontiguousarray(np.stack([synth.synth_lab(rows, cols, 20 + i) for i in range(3)]))
+        with api.Context(0, rows, cols, 3) as c:
+            lab, n, cent = c.slic_labels_dev(torch.from_numpy(imgs).cuda(), step, nc, return_centers=True)
+            torch.cuda.synchronize()
+            got_l, got_c = lab.cpu().numpy(), cent.cpu().numpy()
+            for f in range(3):
+                wl, wn, wc = O.slic(imgs[f], step, nc, return_centers=True)
+                assert wn == n
+                assert np.array_equal(got_l[f], wl), (rows, cols, f, int((got_l[f] != wl).sum()))
+                ok = ~np.isnan(wc[:, 3])
+                assert np.array_equal(got_c[f][ok].view(np.uint64), wc[ok].view(np.uint64))
+            with pytest.raises(api.DcmtError) as e:
+                c.slic_labels_dev(torch.from_numpy(imgs).cuda(), 5, nc)        # the reference's 3x3 probe would leave the image
+            assert e.value.status == L.E_INVALID

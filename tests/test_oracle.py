@@ -238,3 +238,36 @@ def test_n2_projection_goldens_and_rules(golden):
     # full-size sweep: KITTI-like density, and depth = z in the camera frame (third row of P is ~[0 0 1 0])
     full = O.project_points(synth.synth_points(120000, 0), synth.KITTI_T_VELO_TO_CAM, synth.KITTI_P2, 375, 1242)
     assert 0.02 < (full > 0).mean() < 0.06 and full.max() < 81.0
+
+
+def test_n3_slic_goldens_and_properties(golden, golden_meta):
+    """N3 (Slic::generate_superpixels, LC/slic.cpp:101-182): the C oracle against the numpy restatement's goldens
+    (labels and the f64 centres bit for bit), and the properties the algorithm guarantees."""
+    from oracle import oracle as O
+    img = golden["slic_lab96x160"]
+    labels, n, cent = O.slic(img, 12, 40, return_centers=True)
+    assert n == golden_meta["slic96x160_n"] == 12 * 7
+    assert np.array_equal(labels, golden["slic_labels96x160"])
+    want = golden["slic_centers96x160"]
+    dead = np.isnan(want[:, 3])                    # a centre that lost all its pixels is NaN from then on (here: one)
+    assert dead.sum() == 1 and np.array_equal(np.isnan(cent[:, 3]), dead)
+    assert np.array_equal(cent[~dead].view(np.uint64), want[~dead].view(np.uint64))
+    # every centre is the mean of the pixels carrying its label (the last update step), labels are in range
+    assert labels.min() >= -1 and labels.max() < n
+    ys, xs = np.indices(labels.shape)
+    for c in (0, 17, n - 1):
+        m = labels == c
+        assert m.any()
+        assert cent[c, 3] == xs[m].sum() / m.sum() and cent[c, 4] == ys[m].sum() / m.sum()
+        assert cent[c, 0] == img[..., 0][m].astype(np.int64).sum() / m.sum()
+    # a flat image: the colour term vanishes, every pixel takes the spatially nearest centre, ties to the lower index
+    flat = np.full((60, 90, 3), 128, np.uint8)
+    lf, nf, cf = O.slic(flat, 10, 40, return_centers=True)
+    d2 = (cf[:, 3][None, None, :] - np.indices((60, 90))[1][..., None]) ** 2 + (cf[:, 4][None, None, :] - np.indices((60, 90))[0][..., None]) ** 2
+    assert np.array_equal(lf, d2.argmin(axis=2).astype(np.int32))          # converged: labels = Voronoi cells of the final centres
+    assert_bit_equal(O.interpolate_with_superpixels(synth_frame_96(), labels, n), golden["slic_chain96x160"], "labels -> LC chain")
+
+
+def synth_frame_96():
+    from depth_completion_mt_amd import synth
+    return synth.synth_frame(96, 160, 5)
