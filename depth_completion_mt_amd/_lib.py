@@ -27,7 +27,7 @@ EXPORTS = (
     "dcmt_k0_diamond", "dcmt_complete_f32", "dcmt_complete_f32_dev", "dcmt_complete_labeled_f32",
     "dcmt_complete_labeled_f32_dev", "dcmt_complete_u16_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
     "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version", "dcmt_project_points_dev",
-    "dcmt_slic_num_centers", "dcmt_slic_labels_dev",
+    "dcmt_slic_num_centers", "dcmt_slic_labels_dev", "dcmt_default_stereo_params", "dcmt_stereo_refine_dev",
 )
 
 
@@ -47,6 +47,12 @@ class Params(ctypes.Structure):
         ("norm_lo", ctypes.c_float),
         ("norm_hi", ctypes.c_float),
     ]
+
+
+class StereoParams(ctypes.Structure):
+    """Mirror of dcmt_stereo_params (include/dcmt.h)."""
+    _fields_ = [("baseline", ctypes.c_float), ("focal", ctypes.c_float), ("damp", ctypes.c_float),
+                ("max_depth", ctypes.c_float), ("iterations", ctypes.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -108,6 +114,9 @@ def lib() -> ctypes.CDLL:
         L.dcmt_complete_labeled_f32_dev.argtypes = [vp, vp, vp, i, vp, i, i, i, pp, i, vp]
         L.dcmt_complete_u16_dev.argtypes = [vp, vp, ctypes.c_float, vp, i, i, i, pp, vp]
         L.dcmt_project_points_dev.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, i, vp]
+        L.dcmt_default_stereo_params.argtypes = [vp]
+        L.dcmt_default_stereo_params.restype = None
+        L.dcmt_stereo_refine_dev.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, vp]
         L.dcmt_slic_num_centers.argtypes = [i, i, i]
         L.dcmt_slic_labels_dev.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
         L.dcmt_last_fill_iters.argtypes = [vp, ip, i]

@@ -200,6 +200,31 @@ class Context:
             raise DcmtError(st, "dcmt_slic_labels_dev")
         return (d_labels, n, d_cent[:, :n]) if return_centers else (d_labels, n)
 
+    def stereo_refine_dev(self, d_depth, d_left, d_right, d_out=None, iterations: int | None = None, stream: int | None = None, **kw):
+        """N4 (SL/main_sl.cpp:715-885): dense depth + grey stereo pair (uint8 CUDA tensors) -> refined depth.
+        kw: baseline, focal, damp, max_depth override the reference's constants."""
+        import torch
+        assert d_depth.is_cuda and d_depth.dtype == torch.float32 and d_depth.is_contiguous()
+        for t in (d_left, d_right):
+            assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.shape == d_depth.shape
+        shp = d_depth.shape if d_depth.dim() == 3 else (1,) + tuple(d_depth.shape)
+        b, r, c = shp
+        if d_out is None:
+            d_out = torch.full_like(d_depth, float("nan"))
+        sp = L.StereoParams()
+        L.lib().dcmt_default_stereo_params(ctypes.byref(sp))
+        for k, v in kw.items():
+            setattr(sp, k, float(v))
+        if iterations is not None:
+            sp.iterations = int(iterations)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_depth.device).cuda_stream
+        st = L.lib().dcmt_stereo_refine_dev(self._h, d_depth.data_ptr(), d_left.data_ptr(), d_right.data_ptr(), d_out.data_ptr(),
+                                            r, c, b, ctypes.byref(sp), ctypes.c_void_p(stream))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_stereo_refine_dev")
+        return d_out
+
     def last_fill_iters(self, n: int):
         out = (ctypes.c_int * n)()
         st = L.lib().dcmt_last_fill_iters(self._h, out, n)

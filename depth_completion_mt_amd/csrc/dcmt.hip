@@ -634,6 +634,30 @@ int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t*
     return DCMT_OK;
 }
 
+void dcmt_default_stereo_params(dcmt_stereo_params* p)
+{
+    p->baseline = 0.54f;          // SL/main_sl.cpp:847
+    p->focal = 9.597910e+02f;     // :848
+    p->damp = 500.0f;             // :808
+    p->max_depth = 100.0f;        // :876
+    p->iterations = 4;            // :805
+}
+
+int dcmt_stereo_refine_dev(dcmt_ctx* ctx, const float* d_depth, const uint8_t* d_left, const uint8_t* d_right, float* d_refined,
+                           int rows, int cols, int batch, const dcmt_stereo_params* params, void* stream)
+{
+    if (!ctx || !d_depth || !d_left || !d_right || !d_refined || !params) return DCMT_E_INVALID;
+    if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
+    if (params->iterations > 1000) return DCMT_E_INVALID;
+    StereoP P{params->baseline, params->focal, params->damp, params->max_depth, params->iterations < 0 ? 4 : params->iterations};
+    size_t blocks = ((size_t)batch * rows * cols + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_stereo_refine, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_depth, d_left, d_right, d_refined,
+                       rows, cols, batch, P);
+    DCMT_HIP(ctx, hipGetLastError());
+    return DCMT_OK;
+}
+
 int dcmt_slic_num_centers(int rows, int cols, int step)
 {
     if (rows < 1 || cols < 1 || step < 1) return 0;

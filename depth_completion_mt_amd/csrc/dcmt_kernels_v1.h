@@ -189,6 +189,62 @@ void k_project_resolve(const float* __restrict__ pts, const int* __restrict__ of
 }
 
 // ---------------------------------------------------------------------------------
+// N4: the stereo photometric refinement behind the path (SL/main_sl.cpp:715-885, driven from :1165-1246).  One thread
+// per pixel runs all sweeps for its own disparity; the images are read as bytes and the EntryType fields (value,
+// d/dx) are formed on the fly: value = the grey byte, derivative.x = .5 * right - .5 * left neighbour for interior
+// pixels (rows 1..R-2, cols 1..C-2), 0 on the border (:719-745; byte-valued, so exact in f32).
+// calculateObservationDerivatives (:749-801) as called from optimize_IG: r = i exactly, so r0 = i, dr = 0, dr1 = 1 and
+// the lower row of the bilinear patch carries weight 0 -- only row i matters; c0 = (int)(c + 0.5) (a double sum,
+// truncated), accepted when 0 <= c0 and c0 + 1 <= cols, and `at<>(r0, cols)` for c0 + 1 == cols is the next element in
+// memory, i.e. the first pixel of the next row (past the buffer for the last row: that one pixel is left as it is).
+// f32 arithmetic, one rounding per operation, in the reference's order.
+// ---------------------------------------------------------------------------------
+struct StereoP { float baseline, focal, damp, max_depth; int iterations; };
+
+__device__ __forceinline__ float grey_dx(const uint8_t* g, int r, int c, int rows, int cols)
+{
+    if (r < 1 || r >= rows - 1 || c < 1 || c >= cols - 1) return 0.0f;
+    return __fsub_rn(__fmul_rn(0.5f, (float)g[(size_t)r * cols + c + 1]), __fmul_rn(0.5f, (float)g[(size_t)r * cols + c - 1]));
+}
+
+__global__ __launch_bounds__(256)
+void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                     float* __restrict__ out, int rows, int cols, int batch, StereoP P)
+{
+    const size_t fe = (size_t)rows * cols, n = fe * batch;
+    const float bf = __fmul_rn(P.baseline, P.focal);
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const size_t f = idx / fe, rem = idx - f * fe;
+        const int i = (int)(rem / cols), j = (int)(rem - (size_t)i * cols);
+        const uint8_t* gr = right + f * fe;
+        const float d0 = depth[idx];
+        float disp = d0 > 0.0f ? __fdiv_rn(bf, d0) : 0.0f;                      // get_initial_disparity :852-856
+        const float lv = (float)left[idx];
+        for (int k = 0; k < P.iterations; ++k) {                                // optimize_IG :809-841
+            const float c = __fsub_rn((float)j, disp);
+            const int c0 = (int)((double)c + 0.5);
+            if (c0 < 0 || c0 + 1 > cols || disp == 0.0f) continue;
+            const size_t e0 = (size_t)i * cols + c0, e1 = e0 + 1;              // p00, p01 (p01 may be the next row's first pixel)
+            if (e1 >= fe) continue;
+            const int r1 = (int)(e1 / cols), c1 = (int)(e1 - (size_t)r1 * cols);
+            const float dc = __fsub_rn(c, (float)c0), dc1 = __fsub_rn(1.0f, dc);
+            const float value = __fadd_rn(__fmul_rn((float)gr[e0], dc1), __fmul_rn((float)gr[e1], dc));
+            const float dx = __fadd_rn(__fmul_rn(grey_dx(gr, i, c0, rows, cols), dc1), __fmul_rn(grey_dx(gr, r1, c1, rows, cols), dc));
+            float error = __fsub_rn(value, lv);                                 // :819
+            error = error > 255.0f ? 255.0f : error;
+            error = error < -255.0f ? -255.0f : error;
+            const float jcr = __fmul_rn(-1.0f, dx);                             // J = -1 (:830-832)
+            const float H = __fadd_rn(__fmul_rn(jcr, jcr), P.damp);
+            const float b = __fmul_rn(jcr, error);
+            disp = __fadd_rn(disp, __fdiv_rn(-b, H));                           // :836-837
+        }
+        float o = 0.0f;                                                         // retrieve_optimized_depth :868-880
+        if (disp > 0.0f) { o = __fdiv_rn(bf, disp); if (o > P.max_depth) o = P.max_depth; }
+        out[idx] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // init: column statistics and counters for one call
 // ---------------------------------------------------------------------------------
 __global__ void k_init(int* __restrict__ colstat, int* __restrict__ counters, int cols, int batch)

@@ -116,3 +116,23 @@ def synth_lab(rows: int, cols: int, seed: int) -> np.ndarray:
         img[r0:r1, c0:c1] = g.uniform(20, 235, 3)
     img += g.normal(0, 2.0, img.shape)
     return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+
+
+def synth_stereo(rows: int, cols: int, seed: int, baseline: float = 0.54, focal: float = 959.791):
+    """(left uint8 [rows][cols], right uint8, depth_guess f32): a textured scene (sum of random sinusoids, so it can be
+    sampled at fractional positions) seen by a rectified pair; the right image shows the texture shifted by the true
+    disparity, and the depth guess is the true depth with a few per cent of smooth error -- what the stereo
+    refinement (N4) starts from.  Some guess pixels are 0 (no depth), as in the path's all-zero columns."""
+    g = np.random.Generator(np.random.PCG64(seed + 104729))
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    depth = 6.0 + 60.0 * (1.0 - yy / rows) ** 2 + 4.0 * np.sin(xx / 90.0 + seed)          # far at the top, near at the bottom
+    depth[rows // 3: rows // 2, cols // 4: cols // 3] = 9.0                                # a near object: a disparity step
+    disp = baseline * focal / depth
+    waves = [(g.uniform(0.02, 0.35), g.uniform(0.02, 0.35), g.uniform(0, 6.28), g.uniform(8, 30)) for _ in range(10)]
+    tex = lambda x, y: 128.0 + sum(a * np.sin(fx * x + fy * y + ph) for fx, fy, ph, a in waves)
+    left = np.clip(np.rint(tex(xx, yy) + g.normal(0, 1.0, (rows, cols))), 0, 255).astype(np.uint8)
+    right = np.clip(np.rint(tex(xx + disp, yy) + g.normal(0, 1.0, (rows, cols))), 0, 255).astype(np.uint8)
+    guess = (depth * (1.0 + 0.04 * np.sin(xx / 37.0) * np.cos(yy / 23.0))).astype(np.float32)
+    guess[:, : cols // 50] = 0.0
+    guess[g.random((rows, cols)) < 0.002] = 0.0
+    return np.ascontiguousarray(left), np.ascontiguousarray(right), np.ascontiguousarray(guess)

@@ -205,6 +205,29 @@ int dcmt_slic_num_centers(int rows, int cols, int step);
 int dcmt_slic_labels_dev(dcmt_ctx *ctx, const uint8_t *d_lab, int rows, int cols, int batch, int step, int nc,
                          int32_t *d_labels, double *d_centers, void *stream);
 
+/* ---- consumer of the path's output: stereo photometric refinement (N4) ----------------- */
+
+/* What DC_stereo_lidar/main_sl.cpp does with the dense depth (:1165-1246): depth -> disparity (get_initial_disparity
+ * :846-861), four damped Gauss-Newton sweeps that move every pixel's disparity along its epipolar line so that the right
+ * image matches the left one (optimize_IG :804-843 with calculateObservationDerivatives :749-801 on images whose
+ * derivatives calculateMeasuementDerivatives :715-747 made), disparity -> depth clamped to max_depth
+ * (retrieve_optimized_depth :863-885).  Every pixel only ever touches its own disparity, so the sweeps are independent
+ * per pixel.  d_left / d_right: [batch][rows][cols] uint8 grey images (the reference's cv::cvtColor(BGR2GRAY) outputs,
+ * :1167-1171); d_depth: the path's output; d_refined: [batch][rows][cols] f32, 0 where the disparity ends up <= 0.
+ * iterations < 0 selects the reference's 4; iterations == 0 is the pure depth -> disparity -> depth round trip
+ * (its `depth_pre_optim`, :1225-1226). */
+typedef struct {
+    float   baseline;      /* 0.54f          :847 */
+    float   focal;         /* 9.597910e+02f  :848 */
+    float   damp;          /* 500            :808 */
+    float   max_depth;     /* 100            :876 */
+    int32_t iterations;    /* 4              :805 */
+} dcmt_stereo_params;
+void dcmt_default_stereo_params(dcmt_stereo_params *p);
+int dcmt_stereo_refine_dev(dcmt_ctx *ctx, const float *d_depth, const uint8_t *d_left, const uint8_t *d_right,
+                           float *d_refined, int rows, int cols, int batch, const dcmt_stereo_params *params,
+                           void *stream);
+
 /* ---- probes ------------------------------------------------------------------------ */
 
 /* Per frame of the last call on ctx: the number of iterations the reference's while-loop

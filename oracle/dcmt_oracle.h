@@ -111,6 +111,13 @@ void dcmt_oracle_project_points(const float *points, int n, const float T[16], c
 int dcmt_oracle_slic(const uint8_t *lab, int rows, int cols, int step, int nc, int32_t *labels,
                      double *centers, int max_centers);
 
+/* N4: the stereo refinement behind the path (DC_stereo_lidar/main_sl.cpp:715-885 as driven from :1165-1246):
+ * depth -> disparity, `iterations` damped Gauss-Newton sweeps per pixel against the right grey image, disparity -> depth
+ * clamped to max_depth.  left / right: uint8 [rows][cols]; dst f32 [rows][cols]. */
+void dcmt_oracle_stereo_refine(const float *depth, const uint8_t *left, const uint8_t *right, float *dst,
+                               int rows, int cols, float baseline, float focal, float damp, float max_depth,
+                               int iterations);
+
 /* Deterministic KITTI-like synthetic sparse frame. */
 void dcmt_oracle_synth_frame(float *dst, int rows, int cols, uint64_t seed);
 

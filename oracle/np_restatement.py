@@ -196,6 +196,46 @@ def slic(lab, step, nc, iterations=10):
     return labels, n, C
 
 
+def stereo_refine(depth, left, right, baseline=0.54, focal=9.597910e+02, damp=500.0, max_depth=100.0, iterations=4):
+    """N4, SL/main_sl.cpp:715-885 as driven from :1165-1246, whole-array: every pixel only touches its own disparity, so
+    a sweep is one vector update.  f32 throughout (each numpy op rounds once); see dcmt_oracle.c for the citations."""
+    d = np.asarray(depth, dtype=F32)
+    rows, cols = d.shape
+    fe = rows * cols
+    gl = np.asarray(left, dtype=np.uint8).astype(F32).reshape(-1)
+    gr = np.asarray(right, dtype=np.uint8).astype(F32).reshape(-1)
+    g2 = gr.reshape(rows, cols)
+    dxi = np.zeros((rows, cols), F32)                      # calculateMeasuementDerivatives: interior only
+    dxi[1:-1, 1:-1] = F32(0.5) * g2[1:-1, 2:] - F32(0.5) * g2[1:-1, :-2]
+    dxr = dxi.reshape(-1)
+    bf = F32(baseline) * F32(focal)
+    disp = np.zeros((rows, cols), F32)
+    with np.errstate(divide="ignore"):
+        disp[d > 0] = bf / d[d > 0]
+    ii, jj = np.indices((rows, cols))
+    for _ in range(iterations):
+        c = jj.astype(F32) - disp
+        c0 = np.trunc(c.astype(np.float64) + 0.5).astype(np.int64)
+        e0 = ii * cols + c0
+        e1 = e0 + 1
+        ok = (c0 >= 0) & (c0 + 1 <= cols) & (disp != 0) & (e1 < fe)
+        e0c, e1c = np.where(ok, e0, 0), np.where(ok, e1, 0)
+        dc = c - c0.astype(F32)
+        dc1 = F32(1.0) - dc
+        value = gr[e0c] * dc1 + gr[e1c] * dc
+        dx = dxr[e0c] * dc1 + dxr[e1c] * dc
+        err = np.clip(value - gl.reshape(rows, cols), F32(-255.0), F32(255.0))
+        jcr = F32(-1.0) * dx
+        H = jcr * jcr + F32(damp)
+        b = jcr * err
+        disp = np.where(ok, disp + (-b / H), disp).astype(F32)
+    out = np.zeros((rows, cols), F32)
+    pos = disp > 0
+    with np.errstate(divide="ignore"):
+        out[pos] = np.minimum(bf / disp[pos], F32(max_depth))
+    return out
+
+
 def median5(x):
     """cv::medianBlur(x,x,5) on f32: exact median, BORDER_REPLICATE (LO :170)."""
     R, C = x.shape

@@ -85,6 +85,9 @@ def lib(native: bool = False) -> ctypes.CDLL:
         L.dcmt_oracle_slic.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p,
                                        ctypes.POINTER(ctypes.c_double), ctypes.c_int]
         L.dcmt_oracle_slic.restype = ctypes.c_int
+        L.dcmt_oracle_stereo_refine.argtypes = [fp, u8p, u8p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_int]
+        L.dcmt_oracle_stereo_refine.restype = None
         L.dcmt_oracle_synth_frame.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
         L.dcmt_oracle_synth_frame.restype = None
         _libs[native] = L
@@ -235,6 +238,19 @@ def slic(lab_image, step: int, nc: int, return_centers: bool = False):
     if n < 0:
         raise ValueError("dcmt_oracle_slic: step < 6 or nc < 1")
     return (labels, n, centers[:n].copy()) if return_centers else (labels, n)
+
+
+def stereo_refine(depth, left, right, baseline=0.54, focal=9.597910e+02, damp=500.0, max_depth=100.0, iterations=4):
+    """SL/main_sl.cpp:715-885 as driven from :1165-1246: dense depth + grey stereo pair -> refined depth."""
+    d = _c32(depth)
+    l = np.ascontiguousarray(left, dtype=np.uint8)
+    r = np.ascontiguousarray(right, dtype=np.uint8)
+    assert l.shape == d.shape == r.shape
+    dst = np.empty_like(d)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    lib().dcmt_oracle_stereo_refine(_fp(d), l.ctypes.data_as(u8), r.ctypes.data_as(u8), _fp(dst), d.shape[0], d.shape[1],
+                                    baseline, focal, damp, max_depth, int(iterations))
+    return dst
 
 
 def synth_frame(rows: int, cols: int, seed: int) -> np.ndarray:

@@ -135,6 +135,12 @@ def main():
     meta["slic96x160_n"] = int(sn)
     x = synth.synth_frame(96, 160, 5)
     out["slic_chain96x160"] = N.interpolate_with_superpixels(x, slab, sn)
+    # N4: the stereo refinement behind the path (SL/main_sl.cpp:715-885) on a 48x64 synthetic rectified pair; a smaller
+    # focal length keeps the disparities inside the small image
+    sl, sr, sg = synth.synth_stereo(48, 64, 9, focal=60.0)
+    out["stereo_left48x64"], out["stereo_right48x64"], out["stereo_guess48x64"] = sl, sr, sg
+    out["stereo_refined48x64"] = N.stereo_refine(sg, sl, sr, focal=60.0)
+    out["stereo_roundtrip48x64"] = N.stereo_refine(sg, sl, sr, focal=60.0, iterations=0)
     np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **out)
 
     # full-size frames: checksums only (inputs come from the generator)

@@ -483,3 +483,34 @@ def test_n3_slic_labels_on_the_device(golden, golden_meta, O):
             with pytest.raises(api.DcmtError) as e:
                 c.slic_labels_dev(torch.from_numpy(imgs).cuda(), 5, nc)        # the reference's 3x3 probe would leave the image
             assert e.value.status == L.E_INVALID
+
+
+def test_n4_stereo_refinement_on_the_device(golden, O):
+    """dcmt_stereo_refine_dev = the refinement DC_stereo_lidar runs on the path's output (SL/main_sl.cpp:715-885, driven
+    from :1165-1246): bit-exact against the goldens and the oracle, batched at config 4's size, and chained behind the
+    path on the device (complete -> refine)."""
+    import torch
+    l, r, g = golden["stereo_left48x64"], golden["stereo_right48x64"], golden["stereo_guess48x64"]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    with api.Context(0, 48, 64, 1) as c:
+        got = c.stereo_refine_dev(cu(g), cu(l), cu(r), focal=60.0)
+        pre = c.stereo_refine_dev(cu(g), cu(l), cu(r), focal=60.0, iterations=0)
+        torch.cuda.synchronize()
+        assert_bit_equal(got.cpu().numpy(), golden["stereo_refined48x64"], "refined 48x64")
+        assert_bit_equal(pre.cpu().numpy(), golden["stereo_roundtrip48x64"], "round trip 48x64")
+    rows, cols, n = 375, 1242, 5
+    trip = [synth.synth_stereo(rows, cols, 30 + i) for i in range(n)]
+    L_, R_, G_ = (np.stack([t[k] for t in trip]) for k in range(3))
+    G_[1] = 0                                                         # a frame without any depth stays all zero
+    with api.Context(0, rows, cols, n) as c:
+        got = c.stereo_refine_dev(cu(G_), cu(L_), cu(R_))
+        # the path in front: sparse (4 % of the guess) -> img_completion -> refinement, all on the device
+        sparse = np.where(np.random.default_rng(1).random(G_.shape) < 0.04, G_, 0).astype(np.float32)
+        dense = c.complete_dev(cu(sparse))
+        both = c.stereo_refine_dev(dense, cu(L_), cu(R_))
+        torch.cuda.synchronize()
+        got, dn, both = got.cpu().numpy(), dense.cpu().numpy(), both.cpu().numpy()
+    for f in range(n):
+        assert_bit_equal(got[f], O.stereo_refine(G_[f], L_[f], R_[f]), f"refined frame {f}")
+        assert_bit_equal(both[f], O.stereo_refine(dn[f], L_[f], R_[f]), f"complete -> refine frame {f}")
+    assert not got[1].any()

@@ -271,3 +271,24 @@ def test_n3_slic_goldens_and_properties(golden, golden_meta):
 def synth_frame_96():
     from depth_completion_mt_amd import synth
     return synth.synth_frame(96, 160, 5)
+
+
+def test_n4_stereo_refinement_goldens_and_rules(golden):
+    """N4 (SL/main_sl.cpp:715-885): C oracle == the numpy restatement's goldens; the rules of the reference loop."""
+    from oracle import oracle as O
+    l, r, g = golden["stereo_left48x64"], golden["stereo_right48x64"], golden["stereo_guess48x64"]
+    assert_bit_equal(O.stereo_refine(g, l, r, focal=60.0), golden["stereo_refined48x64"], "refined")
+    rt = O.stereo_refine(g, l, r, focal=60.0, iterations=0)
+    assert_bit_equal(rt, golden["stereo_roundtrip48x64"], "depth -> disparity -> depth")
+    assert (rt[g == 0] == 0).all()                                   # no depth: no disparity, stays 0 (:852, :868)
+    bf = np.float32(0.54) * np.float32(60.0)
+    assert_bit_equal(rt[g > 0], np.minimum(bf / (bf / g[g > 0]), np.float32(100.0)), "round trip arithmetic")
+    # identical images and a guess whose disparity is a whole number of pixels: the photometric error is zero, nothing moves
+    flat = np.full((20, 40), bf / np.float32(3.0), np.float32)
+    same = np.tile(l[:1, :40], (20, 1))
+    shifted = np.roll(same, -3, axis=1)
+    moved = O.stereo_refine(flat, same, shifted, focal=60.0)
+    assert_bit_equal(moved[:, 4:36], O.stereo_refine(flat, same, shifted, focal=60.0, iterations=0)[:, 4:36], "zero error: no update")
+    # a depth beyond max_depth after refinement is capped at 100 (:875-878)
+    far = O.stereo_refine(np.full((20, 40), 400.0, np.float32), same, same, focal=60.0)
+    assert far.max() == 100.0
