@@ -179,6 +179,21 @@ def main():
         elapsed, gpu_ms_per_step = float(t[0]), float(t[1])
 
     extra = {}
+    if rank == 0:
+        # per-kernel split, live: the same batch with stop_after = column extension runs k_pre_s alone (same kernel, same
+        # reads and writes; its output goes to d_dst instead of the scratch plane); k_fp_s = the step minus that.
+        # Outside the timed region; cross-checks the rocprofv3 per-kernel averages in profiles/.
+        pre_params = make_params(stop_after=L.STAGE_EXTEND)
+        for _ in range(2):
+            ctx.complete_dev(d_src, d_dst, pre_params, stream=stream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            ctx.complete_dev(d_src, d_dst, pre_params, stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        pre_ms = e0.elapsed_time(e1) / args.steps
+        extra["per_kernel_ms"] = {"k_pre_s": pre_ms, "k_fp_s_by_difference": gpu_ms_per_step - pre_ms}
     if args.batch1 and rank == 0:
         # BASELINE configs[1]: frames arrive one at a time (batch = 1 per call).  One context + stream per
         # in-flight frame; independent frames overlap on the GPU, each call is still a whole cascade on one frame.
@@ -224,7 +239,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "gpu_ms_per_step": gpu_ms_per_step, "algorithmic_bytes_per_step": B * BYTES_PER_FRAME,
-                         "kernel": "whole cascade per step = k_pre_s + k_fp_s (+ 3 skipped redo launches), HIP events around each step on the launch stream; per-kernel times in profiles/"},
+                         "kernel": "whole cascade per step = k_pre_s + k_fp_s (+ 3 skipped redo launches), HIP events around each step on the launch stream; live per-kernel split in per_kernel_ms, rocprofv3 averages in profiles/"},
             "fill_iters_max": max(iters),
         }
         line.update(extra)
