@@ -17,13 +17,20 @@ def per_kernel(path, counter):
     return acc
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-nsteps = int(sys.argv[3])
+# launches per bench step: k_fp_s runs exactly once per step, so its dispatch count is the number of steps the pass saw;
+# every other kernel's launches per step = its dispatches / that -- except k_pre_s, which bench.py also runs alone for its
+# live per-kernel split (per_kernel_ms): one launch per step by construction.  (argv[3], the step count, is only checked.)
+steps_seen = max(len(v) for k, v in fetch.items() if "k_fp_s" in k)
+if int(sys.argv[3]) != steps_seen:
+    print(f"note: {steps_seen} k_fp_s dispatches seen, {sys.argv[3]} steps + warmup given", file=sys.stderr)
 out = {"kernels": {}, "fetch_correction": "x2 (gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B for 128-B requests)"}
 tot = 0.0
 for k in sorted(set(fetch) | set(write)):
-    fb = 2.0 * 1024.0 * sum(fetch.get(k, [0.0])) / nsteps
-    wb = 1024.0 * sum(write.get(k, [0.0])) / nsteps
-    out["kernels"][k] = {"read_bytes_per_step": fb, "write_bytes_per_step": wb}
+    fv, wv = fetch.get(k, [0.0]), write.get(k, [0.0])
+    per_step = 1.0 if "k_pre_s" in k else len(fv) / steps_seen
+    fb = 2.0 * 1024.0 * (sum(fv) / len(fv)) * per_step
+    wb = 1024.0 * (sum(wv) / len(wv)) * per_step
+    out["kernels"][k] = {"read_bytes_per_step": fb, "write_bytes_per_step": wb, "launches_per_step": per_step}
     tot += fb + wb
 out["hbm_bytes_per_step"] = tot
 path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
