@@ -587,11 +587,17 @@ __device__ __forceinline__ void mid20(const float (&pa)[10], const float (&pb)[1
 #undef DCMT_CX
 #undef DCMT_CMIN
 #undef DCMT_CMAX
-// 6th smallest of sorted C (6) u sorted a (5) = the median of the 25-window
+// 6th smallest of sorted C (6) u sorted a (5) = the median of the 25-window:
+//     min(C5, max(a0,C4), max(a1,C3), max(a2,C2), max(a3,C1), max(a4,C0))
+// folded into five med3: with r >= min(a_i, C_{4-i}) -- which the sortedness of C and a guarantees at every step --
+// min(r, max(a_i, C_{4-i})) = med3(a_i, C_{4-i}, r).  Checked on all sorted 0/1 inputs (min / max / med3 commute with
+// monotone maps, so that proves it for all inputs) and on random floats with ties (tools/gen_median_3in.py).
 __device__ __forceinline__ float final6(const float (&C)[6], const float (&a)[5])
 {
-    return fmin2(fmin3(C[5], fmax2(a[0], C[4]), fmax2(a[1], C[3])),
-                 fmin3(fmax2(a[2], C[2]), fmax2(a[3], C[1]), fmax2(a[4], C[0])));
+    float r = C[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r = __builtin_amdgcn_fmed3f(a[i], C[4 - i], r);
+    return r;
 }
 
 // One pass of the [1 4 6 4 1]/16 filter in the reference order  c*k0 + s1*k1 + s2*k2  (s1, s2 = the already rounded

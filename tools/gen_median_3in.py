@@ -10,7 +10,9 @@ the right order statistics.  min, max and med3 all commute with monotone maps, s
 built from them: checking every pair of SORTED 0/1 input lists (the input class is closed under monotone maps) proves the
 rewritten network for all inputs, ties included.  A random-float cross-check against sorted() runs as well.
 
-MERGE55: 26 -> 20 instructions.  MID20: 36 -> 25.  (Per pair of image rows: 62 -> 45.)
+MERGE55: 26 -> 20 instructions.  MID20: 36 -> 25.  (Per pair of image rows: 62 -> 45.)  The closing selection (the
+6th smallest of the six core statistics and the sorted fifth row) becomes a chain of five med3 by the same argument
+(check_final below; the kernel writes it out by hand): 8 -> 5 per row.
 """
 import itertools, os, random, re
 from collections import Counter
@@ -108,7 +110,27 @@ def emit(name, ops, outs, n_out):
     lines.append("  /* end */")
     return "\n".join(lines)
 
+def check_final():
+    """The closing selection, 6th smallest of sorted C (6) u sorted a (5), as a chain of five med3."""
+    med3 = lambda x, y, z: sorted((x, y, z))[1]
+    def chain(c, a):
+        r = c[5]
+        for i in range(5):
+            r = med3(a[i], c[4 - i], r)
+        return r
+    for i in range(7):
+        for j in range(6):
+            c, a = [0] * (6 - i) + [1] * i, [0] * (5 - j) + [1] * j
+            assert chain(c, a) == sorted(c + a)[5]
+    rnd = random.Random(2)
+    for _ in range(20000):
+        c = sorted(rnd.choice([rnd.random(), rnd.randint(0, 3)]) for _ in range(6))
+        a = sorted(rnd.choice([rnd.random(), rnd.randint(0, 3)]) for _ in range(5))
+        assert chain(c, a) == sorted(c + a)[5]
+    print("FINAL 8 -> 5 (med3 chain)")
+
 def main():
+    check_final()
     hdr = ["/* GENERATED by tools/gen_median_3in.py -- do not edit.  The MERGE55 and MID20 networks of median_shared_nets.h",
            " * rewritten with three-input instructions (min3 / max3 / med3) using the order knowledge of their sorted inputs;",
            " * verified exhaustively (0/1 principle on sorted inputs) and on random floats.  IN(k): k-th input wire (MERGE55: 0-4 = A,",
