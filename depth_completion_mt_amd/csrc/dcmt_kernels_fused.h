@@ -536,10 +536,11 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
 // mode: 9 = stop after the median, 10 = after the blur, 11 = everything
 //
 // The exact median is time-shared down the column (tools/gen_median_shared.py has the scheme
-// and its verification): every row's 5 horizontal neighbours are sorted once (18 min/max),
-// every second row a pair of sorted rows is merged (26) and the six middle order statistics
-// of the 4-row core are extracted (36); each window's median is then the 6th smallest of
-// those six and the sorted fifth row (8).  57 min/max per pixel instead of ~200.
+// and its verification): every row's 5 horizontal neighbours are sorted once (12 three-input
+// instructions), every second row a pair of sorted rows is merged (20) and the six middle order
+// statistics of the 4-row core are extracted (25); each window's median is then the 6th smallest of
+// those six and the sorted fifth row (5).  42.5 instructions per pixel instead of ~200
+// (tools/gen_median_3in.py has the three-input rewriting of the networks and its proof).
 // ---------------------------------------------------------------------------------
 struct PostS {
     static constexpr int H = 4;                  // 2 (median) + 2 (Gaussian) lanes lost per side
