@@ -1,6 +1,7 @@
 // dcmt_kernels_fused.h -- the fast path for the default configuration (a preset first
 // element, images of at least 8x8): two launches per batch (k_pre_s, k_fp_s), the hot
-// stencils held entirely in registers, no barriers, LDS only as wave-private delay lines.
+// stencils held entirely in registers, no barriers, LDS only as wave-private delay lines and
+// row rings; rows addressed through buffer resources (FrameBuf).
 //
 //   k_pre_s   H2..H6   one wave64 owns a strip of columns over the FULL image height and
 //                      streams down the rows: lane = column, vertical windows live in
@@ -335,9 +336,10 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 // Labels are disjoint and each write-back depends only on the pre-loop values of its own label.
 //   k_label_bbox     one pass over the label plane: bounding box of every label (atomics only where a
 //                    run of equal labels starts / ends), and X4 = H2 for the pixels no label claims;
-//   k_label_stage_s  one wave64 per (frame, label): the k_pre_s pipeline (H2, H3, H4) on the masked
-//                    image over the label's bounding box grown by 6, lane = column, rows streamed;
-//                    writes X4 where label == c.  Boxes wider than 52 columns are walked in chunks.
+//   k_label_stage_s  one wave64 per label pair (or per label): the k_pre_s pipeline (H2, H3, H4) on the masked
+//                    image over the label's bounding box grown by the chain's reach, lane = column, rows
+//                    streamed; writes X4 where label == c.  Two boxes that fit side by side share the wave;
+//                    boxes wider than 64 - reach columns are walked in chunks.
 //   k_pre_s<START4>  H5 + H6 on X4, then k_fp_s as for img_completion.
 // ---------------------------------------------------------------------------------
 // LDS_TABLE: the workgroup (64 columns x kBboxRows rows) first reduces into a per-label table in LDS (ds_min /
