@@ -213,15 +213,15 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     const int gxc = min(max(gx, 0), cols - 1);       // loads are unconditional, from clamped addresses
     float na = 1.0f, nb = 0.0f;
     if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
-    const float* sp = src + fo + gxc;
     const uint16_t* sp16 = static_cast<const uint16_t*>(src_) + fo + gxc;
+    FrameBuf ob, ib;                              // the output / input frame; this lane's column at byte offset oc
+    ob.init(x6 + fo, (size_t)rows * cols);
+    ib.init(src + fo, (size_t)rows * cols);
+    const unsigned oc = 4u * (unsigned)gxc;
     auto load_row = [&](int r) -> float {          // image row r (already clamped) of this lane's column
         if constexpr (U16) return __fmul_rn((float)sp16[(size_t)r * cols], in_scale);
-        else return sp[(size_t)r * cols];
+        else return ib.ld(oc, r, cols);
     };
-    FrameBuf ob;                                  // the output frame; this lane's column at byte offset oc
-    ob.init(x6 + fo, (size_t)rows * cols);
-    const unsigned oc = 4u * (unsigned)gxc;
     RowRing<4, ROFF> rr;
     if constexpr (WIDE) rr.init(s_ring + (strip & 3) * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
 
@@ -235,7 +235,10 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 #pragma unroll
     for (int q = 0; q < 8; ++q) { XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; H7[q] = NEG; E4[q] = NEG; PF[q] = 0.f; }
 
-    constexpr int PFD = 4;                       // rows of load lookahead
+#ifndef DCMT_PRE_PFD
+#define DCMT_PRE_PFD 4
+#endif
+    constexpr int PFD = DCMT_PRE_PFD;            // rows of load lookahead (dword path)
     if constexpr (WIDE) {
         rr.issue(0); rr.issue(1); rr.issue(2);   // three 4-row blocks ahead
     } else {
