@@ -292,3 +292,28 @@ def test_n4_stereo_refinement_goldens_and_rules(golden):
     # a depth beyond max_depth after refinement is capped at 100 (:875-878)
     far = O.stereo_refine(np.full((20, 40), 400.0, np.float32), same, same, focal=60.0)
     assert far.max() == 100.0
+
+
+def test_primitives_match_scipy_ndimage():
+    """A third, independently written implementation of the primitives (scipy.ndimage, which shares no code with the two
+    restatements): rectangular dilate / erode with the constant border sentinels, the 5x5 median with replicated border
+    (bit-exact), the [1 4 6 4 1]/16 Gaussian with reflect-101 border (scipy accumulates in f64: within 1e-5), and the
+    as-compiled first element, whose orientation (dst(p) = max src(p + k - anchor), un-reflected) scipy reproduces as
+    a grey dilation with the footprint rotated by 180 degrees."""
+    from scipy import ndimage as ndi
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    x = np.where(rng.random((57, 83)) < 0.3, rng.uniform(0.2, 90.0, (57, 83)), 0.0).astype(np.float32)
+    fmax = np.float32(np.finfo(np.float32).max)
+    for k in (5, 7, 31):
+        assert_bit_equal(O.dilate_rect(x, k), ndi.maximum_filter(x, size=k, mode="constant", cval=-fmax), f"dilate {k}")
+        assert_bit_equal(O.erode_rect(x, k), ndi.minimum_filter(x, size=k, mode="constant", cval=fmax), f"erode {k}")
+    assert_bit_equal(O.median5(x), ndi.median_filter(x, size=5, mode="nearest"), "median 5x5 replicate")
+    taps = np.array([1, 4, 6, 4, 1], np.float64) / 16.0
+    g = ndi.correlate1d(ndi.correlate1d(x.astype(np.float64), taps, axis=1, mode="mirror"), taps, axis=0, mode="mirror")
+    assert np.abs(O.gaussian5(x).astype(np.float64) - g).max() <= 1e-5
+    k0 = O.k0_as_compiled()
+    want = ndi.grey_dilation(x, footprint=k0[::-1, ::-1].astype(bool), mode="constant", cval=-fmax)
+    assert_bit_equal(O.dilate_mask5(x, k0), want, "first element, un-reflected")
+    kd = O.k0_diamond()
+    assert_bit_equal(O.dilate_mask5(x, kd), ndi.grey_dilation(x, footprint=kd.astype(bool), mode="constant", cval=-fmax), "diamond")
