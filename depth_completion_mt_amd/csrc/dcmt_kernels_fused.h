@@ -388,7 +388,13 @@ void k_label_bbox(const float* __restrict__ src, const int32_t* __restrict__ lab
         const int left = __builtin_amdgcn_update_dpp(-2, l, 0x138, 0xf, 0xf, false);   // lane 0 keeps -2: always a run start
         const int right = __builtin_amdgcn_update_dpp(-2, l, 0x130, 0xf, 0xf, false);
         if constexpr (LDS_TABLE) {
-            if (lv && l != left) { atomicMin(&s_bb[4 * l], gy); atomicMax(&s_bb[4 * l + 2], gy); atomicMin(&s_bb[4 * l + 1], gx); }
+            // a run that continues the same label straight above / below cannot move that label's top / bottom row
+            const bool top = r == 0 || lrow[r > 0 ? r - 1 : 0] != l, bot = r == 7 || gy + 1 >= rows || lrow[r < 7 ? r + 1 : 7] != l;
+            if (lv && l != left) {
+                if (top) atomicMin(&s_bb[4 * l], gy);
+                if (bot) atomicMax(&s_bb[4 * l + 2], gy);
+                atomicMin(&s_bb[4 * l + 1], gx);
+            }
             if (lv && l != right) atomicMax(&s_bb[4 * l + 3], gx);
         } else {
             if (lv && l != left) { atomicMin(&mn[2 * l], gy); atomicMax(&mx[2 * l], gy); atomicMin(&mn[2 * l + 1], gx); }
