@@ -52,8 +52,8 @@ struct dcmt_ctx {
     int* bb_max = nullptr;
     size_t bb_ints = 0;
     // N3 (SLIC) scratch, allocated by the first dcmt_slic_labels_dev call
-    unsigned long long* slic_dist = nullptr;    // [max_batch][rows][cols] f64 bits
-    int* slic_new = nullptr;                    // [max_batch][rows][cols]
+    int* slic_cells = nullptr;                  // [max_batch][cells]: centres per cell, then [max_batch][cells][kSlicCellCap] their indices, then [max_batch] overflow flags
+    size_t slic_cell_cap = 0;                   // cells per frame that buffer holds
     double* slic_centers[2] = {nullptr, nullptr};
     unsigned long long* slic_sums = nullptr;
     size_t slic_center_cap = 0;                 // centres per frame the two buffers above hold
@@ -565,7 +565,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
     (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);
-    (void)hipFree(ctx->slic_dist); (void)hipFree(ctx->slic_new); (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]);
+    (void)hipFree(ctx->slic_cells); (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]);
     (void)hipFree(ctx->slic_sums);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     delete ctx;
@@ -678,9 +678,16 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     const size_t px = (size_t)batch * rows * cols;
     if (n == 0) { DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st)); return DCMT_OK; }
     DCMT_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t max_px = ctx->frame_elems * (size_t)ctx->max_batch;
-    if (!ctx->slic_dist) DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_dist, sizeof(unsigned long long) * max_px));
-    if (!ctx->slic_new) DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_new, sizeof(int) * max_px));
+    const int gx = (cols - 1) / step + 1, gy = (rows - 1) / step + 1;       // cells of step x step pixels
+    const size_t cells = (size_t)gx * gy;
+    if (cells > ctx->slic_cell_cap) {
+        (void)hipFree(ctx->slic_cells); ctx->slic_cells = nullptr; ctx->slic_cell_cap = 0;
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_cells, sizeof(int) * ((size_t)ctx->max_batch * cells * (1 + kSlicCellCap) + ctx->max_batch)));
+        ctx->slic_cell_cap = cells;
+    }
+    int* cell_cnt = ctx->slic_cells;                                      // [batch][cells] and, right behind, [batch] overflow flags:
+    int* overflow = cell_cnt + (size_t)batch * cells;                     // one memset clears both
+    int* cell_list = overflow + batch;
     if ((size_t)n > ctx->slic_center_cap) {
         (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]); (void)hipFree(ctx->slic_sums);
         ctx->slic_centers[0] = ctx->slic_centers[1] = nullptr; ctx->slic_sums = nullptr; ctx->slic_center_cap = 0;
@@ -692,18 +699,14 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     }
     DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st));                    // clusters = -1 (slic.cpp:24)
     hipLaunchKernelGGL(k_slic_init, dim3((n + 63) / 64, batch), dim3(64), 0, st, d_lab, ctx->slic_centers[0], rows, cols, step, n);
-    size_t mblocks = (px + 255) / 256;
-    if (mblocks > 16384) mblocks = 16384;
     for (int it = 0; it < 10; ++it) {                                                           // NR_ITERATIONS (slic.h:20)
         double* cur = ctx->slic_centers[it & 1];
         double* nxt = ctx->slic_centers[(it + 1) & 1];
-        DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_dist, 0x7f, sizeof(unsigned long long) * px, st));     // "FLT_MAX": above every distance
-        DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_new, 0x7f, sizeof(int) * px, st));
+        DCMT_HIP(ctx, hipMemsetAsync(cell_cnt, 0, sizeof(int) * ((size_t)batch * cells + batch), st));
         DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_sums, 0, sizeof(unsigned long long) * 6 * (size_t)n * batch, st));
-        hipLaunchKernelGGL((k_slic_dist<false>), dim3(n, batch), dim3(256), 0, st, d_lab, cur, ctx->slic_dist, ctx->slic_new, rows, cols, step, nc, n);
-        hipLaunchKernelGGL((k_slic_dist<true>), dim3(n, batch), dim3(256), 0, st, d_lab, cur, ctx->slic_dist, ctx->slic_new, rows, cols, step, nc, n);
-        hipLaunchKernelGGL(k_slic_accum, dim3(n, batch), dim3(256), 0, st, d_lab, cur, ctx->slic_new, ctx->slic_sums, rows, cols, step, n);
-        hipLaunchKernelGGL(k_slic_merge, dim3((unsigned)mblocks), dim3(256), 0, st, d_lab, ctx->slic_new, d_labels, ctx->slic_sums, rows, cols, n, batch);
+        hipLaunchKernelGGL(k_slic_bin, dim3((n + 63) / 64, batch), dim3(64), 0, st, cur, cell_cnt, cell_list, overflow, step, n, gx, gy);
+        hipLaunchKernelGGL(k_slic_assign, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + kSlicTH - 1) / kSlicTH, batch), dim3(256), 0, st, d_lab, cur,
+                           cell_cnt, cell_list, overflow, d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy);
         hipLaunchKernelGGL(k_slic_norm, dim3((n * batch + 255) / 256), dim3(256), 0, st, ctx->slic_sums, nxt, n * batch);
         DCMT_HIP(ctx, hipGetLastError());
     }

@@ -199,7 +199,8 @@ int dcmt_project_points_dev(dcmt_ctx *ctx, const float *d_points, const int32_t 
  * d_labels: [batch][rows][cols] int32, row-major (the reference's clusters[col][row]), -1 = never reached: exactly what
  * dcmt_complete_labeled_f32_dev takes, with n_labels = dcmt_slic_num_centers(rows, cols, step).
  * d_centers (may be NULL): [batch][n][5] f64 = L, a, b, x, y after the last iteration.
- * The first call allocates SLIC scratch (12 B per pixel of max_batch frames); later calls never allocate.
+ * The first call allocates SLIC scratch (per-centre and per-cell tables, a few hundred KiB per frame of max_batch);
+ * later calls with the same or a larger step never allocate.
  * Requires step >= 6 (below that the reference's gradient probe reads outside the image) and nc >= 1. */
 int dcmt_slic_num_centers(int rows, int cols, int step);
 int dcmt_slic_labels_dev(dcmt_ctx *ctx, const uint8_t *d_lab, int rows, int cols, int batch, int step, int nc,
