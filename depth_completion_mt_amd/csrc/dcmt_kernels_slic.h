@@ -87,7 +87,7 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // smallest q is below every other by more than a factor 1 - 1e-12 the reference's comparison has the same winner.
 // Only candidates inside that band (exact ties included) are evaluated with slic_dist itself and compared as
 // (distance, centre index), which is the reference's rule.
-constexpr int kSlicCellCap = 8;
+constexpr int kSlicCellCap = 4;
 
 __global__ void k_slic_bin(const double* __restrict__ centers, int* __restrict__ cell_cnt, int* __restrict__ cell_list,
                            int* __restrict__ overflow, int step, int n, int gx, int gy)
