@@ -467,6 +467,17 @@ def test_n3_slic_labels_on_the_device(golden, golden_meta, O):
         dense = c.complete_dev(torch.from_numpy(x).cuda()[None], d_labels=lab, n_labels=n, params=api.make_params(force_fused=True))
         torch.cuda.synchronize()
         assert_bit_equal(dense.cpu().numpy()[0], golden["slic_chain96x160"], "SLIC -> interpolate_with_superpixels")
+    # tiny steps: a tile then spans more cells than are staged in LDS and its pixels walk all centres from global
+    # memory (the same walk a cell-list overflow falls back to); steps that do not divide the tile size
+    for step, nc in ((6, 40), (7, 10), (11, 25)):
+        img = np.ascontiguousarray(synth.synth_lab(75, 131, 40 + step))
+        with api.Context(0, 75, 131, 1) as c:
+            lab, n, cent = c.slic_labels_dev(torch.from_numpy(img).cuda(), step, nc, return_centers=True)
+            torch.cuda.synchronize()
+            wl, wn, wc = O.slic(img, step, nc, return_centers=True)
+            assert wn == n and np.array_equal(lab.cpu().numpy()[0], wl), (step, int((lab.cpu().numpy()[0] != wl).sum()))
+            ok = ~np.isnan(wc[:, 3])
+            assert np.array_equal(cent.cpu().numpy()[0][ok].view(np.uint64), wc[ok].view(np.uint64))
     for rows, cols, nsp, nc in ((352, 1216, 1200, 50), (375, 1242, 100, 40)):
         step = int(np.sqrt(rows * cols / nsp))                        # the callers' double step, truncated at the call
         imgs = np.ascontiguousarray(np.stack([synth.synth_lab(rows, cols, 20 + i) for i in range(3)]))
