@@ -678,7 +678,9 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     const size_t px = (size_t)batch * rows * cols;
     if (n == 0) { DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st)); return DCMT_OK; }
     DCMT_HIP(ctx, hipSetDevice(ctx->device));
-    const int gx = (cols - 1) / step + 1, gy = (rows - 1) / step + 1;       // cells of step x step pixels
+    int cell_px = step;                                                    // cells of step x step pixels
+    { const char* e = std::getenv("DCMT_SLIC_CELL_SCALE"); if (e && std::atoi(e) > 1) cell_px = step * std::atoi(e); }   // tests: crowded cells
+    const int gx = (cols - 1) / cell_px + 1, gy = (rows - 1) / cell_px + 1;
     const size_t cells = (size_t)gx * gy;
     if (cells > ctx->slic_cell_cap) {
         (void)hipFree(ctx->slic_cells); ctx->slic_cells = nullptr; ctx->slic_cell_cap = 0;
@@ -704,9 +706,9 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
         double* nxt = ctx->slic_centers[(it + 1) & 1];
         DCMT_HIP(ctx, hipMemsetAsync(cell_cnt, 0, sizeof(int) * ((size_t)batch * cells + batch), st));
         DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_sums, 0, sizeof(unsigned long long) * 6 * (size_t)n * batch, st));
-        hipLaunchKernelGGL(k_slic_bin, dim3((n + 63) / 64, batch), dim3(64), 0, st, cur, cell_cnt, cell_list, overflow, step, n, gx, gy);
+        hipLaunchKernelGGL(k_slic_bin, dim3((n + 63) / 64, batch), dim3(64), 0, st, cur, cell_cnt, cell_list, overflow, cell_px, n, gx, gy);
         hipLaunchKernelGGL(k_slic_assign, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + kSlicTH - 1) / kSlicTH, batch), dim3(256), 0, st, d_lab, cur,
-                           cell_cnt, cell_list, overflow, d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy);
+                           cell_cnt, cell_list, overflow, d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
         hipLaunchKernelGGL(k_slic_norm, dim3((n * batch + 255) / 256), dim3(256), 0, st, ctx->slic_sums, nxt, n * batch);
         DCMT_HIP(ctx, hipGetLastError());
     }

@@ -76,7 +76,8 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 }
 
 // ---- pixel-major assignment -------------------------------------------------------------------------------------
-// Centres are binned into cells of step x step pixels (k_slic_bin: per cell a count and up to kSlicCellCap indices);
+// Centres are binned into cells of cell_px x cell_px pixels, cell_px = step (any cell_px >= step is correct: tests use
+// larger cells to force list overflows) (k_slic_bin: per cell a count and up to kSlicCellCap indices);
 // a centre whose window [c - step, c + step) contains pixel x has floor(c / step) within one cell of floor(x / step),
 // so every pixel looks at the 3 x 3 cells around its own.  If any cell of a frame overflows its list, the frame's
 // pixels walk all centres instead (correct, slow, never seen on SLIC-like data).
@@ -90,13 +91,13 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 constexpr int kSlicCellCap = 4;
 
 __global__ void k_slic_bin(const double* __restrict__ centers, int* __restrict__ cell_cnt, int* __restrict__ cell_list,
-                           int* __restrict__ overflow, int step, int n, int gx, int gy)
+                           int* __restrict__ overflow, int cell_px, int n, int gx, int gy)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (j >= n) return;
     const double* C = centers + ((size_t)f * n + j) * 5;
     if (__builtin_bit_cast(unsigned long long, C[3]) == kSlicDead) return;
-    const int cx = min(max((int)(C[3] / (double)step), 0), gx - 1), cy = min(max((int)(C[4] / (double)step), 0), gy - 1);
+    const int cx = min(max((int)(C[3] / (double)cell_px), 0), gx - 1), cy = min(max((int)(C[4] / (double)cell_px), 0), gy - 1);
     const size_t cell = ((size_t)f * gy + cy) * gx + cx;
     const int slot = atomicAdd(&cell_cnt[cell], 1);
     if (slot < kSlicCellCap) cell_list[cell * kSlicCellCap + slot] = j;
@@ -115,15 +116,15 @@ constexpr int kSlicTW = 64, kSlicTH = 16, kSlicMaxCells = 64;   // 35 KB of LDS;
 __global__ __launch_bounds__(256)
 void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ centers, const int* __restrict__ cell_cnt,
                    const int* __restrict__ cell_list, const int* __restrict__ overflow, int* __restrict__ labels,
-                   unsigned long long* __restrict__ sums, int rows, int cols, int step, int nc, int n, int gx, int gy)
+                   unsigned long long* __restrict__ sums, int rows, int cols, int step, int nc, int n, int gx, int gy, int cell_px)
 {
     __shared__ double s_c[kSlicMaxCells * kSlicCellCap][5];
     __shared__ int s_idx[kSlicMaxCells * kSlicCellCap];
     __shared__ unsigned s_acc[kSlicMaxCells * kSlicCellCap][6];
     __shared__ int s_cnt[kSlicMaxCells];
     const int f = blockIdx.z, tx0 = blockIdx.x * kSlicTW, ty0 = blockIdx.y * kSlicTH;
-    const int cxa = max(tx0 / step - 1, 0), cxb = min((min(tx0 + kSlicTW, cols) - 1) / step + 1, gx - 1);
-    const int cya = max(ty0 / step - 1, 0), cyb = min((min(ty0 + kSlicTH, rows) - 1) / step + 1, gy - 1);
+    const int cxa = max(tx0 / cell_px - 1, 0), cxb = min((min(tx0 + kSlicTW, cols) - 1) / cell_px + 1, gx - 1);
+    const int cya = max(ty0 / cell_px - 1, 0), cyb = min((min(ty0 + kSlicTH, rows) - 1) / cell_px + 1, gy - 1);
     const int ncx = cxb - cxa + 1, ncells = ncx * (cyb - cya + 1);
     const bool all = overflow[f] != 0 || ncells > kSlicMaxCells;       // walk every centre from global memory instead
     const double* CF = centers + (size_t)f * n * 5;
@@ -170,7 +171,7 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
         int e1 = -1;                                // entry (LDS slot, or centre index in the `all` walk) of the smallest
         auto sweep = [&](auto&& visit) {
             if (all) { for (int j = 0; j < n; ++j) visit(CF + (size_t)j * 5, j, false); return; }
-            const int lcx = x / step - cxa, lcy = y / step - cya;
+            const int lcx = x / cell_px - cxa, lcy = y / cell_px - cya;
             for (int cy = max(lcy - 1, 0); cy <= min(lcy + 1, cyb - cya); ++cy)
                 for (int cx = max(lcx - 1, 0); cx <= min(lcx + 1, ncx - 1); ++cx) {
                     const int c = cy * ncx + cx;

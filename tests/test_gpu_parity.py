@@ -496,6 +496,29 @@ def test_n3_slic_labels_on_the_device(golden, golden_meta, O):
             assert e.value.status == L.E_INVALID
 
 
+def test_n3_slic_cell_list_overflow_falls_back_to_the_full_walk():
+    """With cells twice / three times the step, four or nine centres share a cell, the 4-entry lists overflow and
+    the frame walks all centres; with ample cells (scale 1) nothing overflows.  Same labels either way."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np, torch
+        from depth_completion_mt_amd import Context, synth
+        from oracle import oracle as O
+        img = np.ascontiguousarray(synth.synth_lab(120, 200, 3))
+        with Context(0, 120, 200, 1) as c:
+            lab, n = c.slic_labels_dev(torch.from_numpy(img).cuda(), 12, 40)
+            torch.cuda.synchronize()
+        wl, wn = O.slic(img, 12, 40)
+        assert n == wn and np.array_equal(lab.cpu().numpy()[0], wl)
+        print("OK")
+    """)
+    for scale in ("1", "2", "3"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DCMT_SLIC_CELL_SCALE=scale), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, (scale, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_n4_stereo_refinement_on_the_device(golden, O):
     """dcmt_stereo_refine_dev = the refinement DC_stereo_lidar runs on the path's output (SL/main_sl.cpp:715-885, driven
     from :1165-1246): bit-exact against the goldens and the oracle, batched at config 4's size, and chained behind the
