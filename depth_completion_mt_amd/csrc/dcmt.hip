@@ -520,6 +520,7 @@ void dcmt_default_params(dcmt_params* p)
 int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx** out)
 {
     if (!out || max_rows < 1 || max_cols < 1 || max_batch < 1 || max_batch > 65535) return DCMT_E_INVALID;
+    if ((size_t)max_rows * (size_t)max_cols > (size_t)0x1fffffff) return DCMT_E_INVALID;   // a frame is addressed with 32-bit byte offsets
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return DCMT_E_NO_DEVICE;

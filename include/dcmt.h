@@ -110,7 +110,8 @@ int dcmt_device_count(void);
 
 /* Creates a context on `device` able to process up to max_batch frames of up to
  * max_rows x max_cols per call.  Allocates all device scratch up front (about
- * 12 B per pixel per frame of max_batch) so the call path never allocates. */
+ * 12 B per pixel per frame of max_batch) so the call path never allocates.  A frame may hold at most 2^29 - 1
+ * pixels (it is addressed with 32-bit byte offsets); max_batch at most 65535. */
 int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx **out);
 void dcmt_destroy(dcmt_ctx *ctx);
 

@@ -64,6 +64,14 @@ def test_null_and_range_validation_without_gpu():
     h = ctypes.c_void_p()
     assert lib.dcmt_create(0, 0, 10, 1, ctypes.byref(h)) == L.E_INVALID
     assert lib.dcmt_create(0, 10, 10, 1, None) == L.E_INVALID
+    assert lib.dcmt_create(0, 1 << 15, 1 << 15, 1, ctypes.byref(h)) == L.E_INVALID     # 2^30 pixels: beyond 32-bit byte offsets
+    assert lib.dcmt_slic_num_centers(352, 1216, 18) == 67 * 19 and lib.dcmt_slic_num_centers(375, 1242, 68) == 17 * 5
+    assert lib.dcmt_slic_labels_dev(None, None, 8, 8, 1, 6, 1, None, None, None) == L.E_INVALID
+    assert lib.dcmt_project_points_dev(None, None, None, 0, 1, None, None, None, 8, 8, None) == L.E_INVALID
+    assert lib.dcmt_stereo_refine_dev(None, None, None, None, None, 8, 8, 1, None, None) == L.E_INVALID
+    sp = L.StereoParams()
+    lib.dcmt_default_stereo_params(ctypes.byref(sp))
+    assert (round(sp.baseline, 2), round(sp.focal, 3), sp.damp, sp.max_depth, sp.iterations) == (0.54, 959.791, 500.0, 100.0, 4)
     p = api.make_params()
     assert lib.dcmt_complete_f32_dev(None, None, None, 1, 1, 1, ctypes.byref(p), None) == L.E_INVALID
     assert lib.dcmt_last_fill_iters(None, None, 0) == L.E_INVALID
