@@ -28,6 +28,7 @@ EXPORTS = (
     "dcmt_complete_labeled_f32_dev", "dcmt_complete_u16_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
     "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version", "dcmt_project_points_dev",
     "dcmt_slic_num_centers", "dcmt_slic_labels_dev", "dcmt_default_stereo_params", "dcmt_stereo_refine_dev",
+    "dcmt_project_points", "dcmt_slic_labels", "dcmt_stereo_refine",
 )
 
 
@@ -117,6 +118,9 @@ def lib() -> ctypes.CDLL:
         L.dcmt_default_stereo_params.argtypes = [vp]
         L.dcmt_default_stereo_params.restype = None
         L.dcmt_stereo_refine_dev.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, vp]
+        L.dcmt_project_points.argtypes = [vp, vp, i, vp, vp, vp, sz, i, i]
+        L.dcmt_slic_labels.argtypes = [vp, vp, sz, i, i, i, i, vp, vp]
+        L.dcmt_stereo_refine.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, i, i, vp]
         L.dcmt_slic_num_centers.argtypes = [i, i, i]
         L.dcmt_slic_labels_dev.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
         L.dcmt_last_fill_iters.argtypes = [vp, ip, i]

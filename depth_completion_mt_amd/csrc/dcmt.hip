@@ -718,6 +718,86 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     return DCMT_OK;
 }
 
+// ---- host variants of N2 / N3 / N4: temporary device buffers, synchronous ----------------------------------------
+namespace {
+struct DevBuf {                                    // freed when the call returns, whatever path it takes
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(dcmt_ctx* ctx, size_t bytes) { DCMT_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1)); return DCMT_OK; }
+};
+int host_stream(dcmt_ctx* ctx, hipStream_t* st)
+{
+    DCMT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->own_stream) DCMT_HIP(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    *st = ctx->own_stream;
+    return DCMT_OK;
+}
+}  // namespace
+
+int dcmt_project_points(dcmt_ctx* ctx, const float* points, int n_points, const float T[16], const float P[12],
+                        float* sparse, size_t srs, int rows, int cols)
+{
+    if (!ctx || !sparse || !T || !P || n_points < 0 || (n_points > 0 && !points) || rows < 1 || cols < 1) return DCMT_E_INVALID;
+    if (srs < sizeof(float) * (size_t)cols) return DCMT_E_INVALID;
+    hipStream_t st;
+    int rc = host_stream(ctx, &st);
+    if (rc != DCMT_OK) return rc;
+    DevBuf dp, doff, dout;
+    const size_t row_b = sizeof(float) * (size_t)cols;
+    if ((rc = dp.alloc(ctx, sizeof(float) * 4 * (size_t)n_points)) != DCMT_OK || (rc = doff.alloc(ctx, sizeof(int32_t) * 2)) != DCMT_OK ||
+        (rc = dout.alloc(ctx, row_b * rows)) != DCMT_OK) return rc;
+    const int32_t off[2] = {0, n_points};
+    if (n_points) DCMT_HIP(ctx, hipMemcpyAsync(dp.p, points, sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, st));
+    DCMT_HIP(ctx, hipMemcpyAsync(doff.p, off, sizeof(off), hipMemcpyHostToDevice, st));
+    rc = dcmt_project_points_dev(ctx, (const float*)dp.p, (const int32_t*)doff.p, n_points, 1, T, P, (float*)dout.p, rows, cols, st);
+    if (rc != DCMT_OK) return rc;
+    DCMT_HIP(ctx, hipMemcpy2DAsync(sparse, srs, dout.p, row_b, row_b, rows, hipMemcpyDeviceToHost, st));
+    DCMT_HIP(ctx, hipStreamSynchronize(st));
+    return DCMT_OK;
+}
+
+int dcmt_slic_labels(dcmt_ctx* ctx, const uint8_t* lab, size_t lrs, int rows, int cols, int step, int nc, int32_t* labels, double* centers)
+{
+    if (!ctx || !lab || !labels || rows < 1 || cols < 1 || lrs < 3 * (size_t)cols) return DCMT_E_INVALID;
+    hipStream_t st;
+    int rc = host_stream(ctx, &st);
+    if (rc != DCMT_OK) return rc;
+    const int n = dcmt_slic_num_centers(rows, cols, step);
+    DevBuf dl, dlab, dc;
+    const size_t row_b = 3 * (size_t)cols, px = (size_t)rows * cols;
+    if ((rc = dl.alloc(ctx, row_b * rows)) != DCMT_OK || (rc = dlab.alloc(ctx, sizeof(int32_t) * px)) != DCMT_OK ||
+        (rc = dc.alloc(ctx, sizeof(double) * 5 * (size_t)(n > 0 ? n : 1))) != DCMT_OK) return rc;
+    DCMT_HIP(ctx, hipMemcpy2DAsync(dl.p, row_b, lab, lrs, row_b, rows, hipMemcpyHostToDevice, st));
+    rc = dcmt_slic_labels_dev(ctx, (const uint8_t*)dl.p, rows, cols, 1, step, nc, (int32_t*)dlab.p, centers ? (double*)dc.p : nullptr, st);
+    if (rc != DCMT_OK) return rc;
+    DCMT_HIP(ctx, hipMemcpyAsync(labels, dlab.p, sizeof(int32_t) * px, hipMemcpyDeviceToHost, st));
+    if (centers && n > 0) DCMT_HIP(ctx, hipMemcpyAsync(centers, dc.p, sizeof(double) * 5 * (size_t)n, hipMemcpyDeviceToHost, st));
+    DCMT_HIP(ctx, hipStreamSynchronize(st));
+    return DCMT_OK;
+}
+
+int dcmt_stereo_refine(dcmt_ctx* ctx, const float* depth, size_t drs, const uint8_t* left, size_t lrs, const uint8_t* right, size_t rrs,
+                       float* refined, size_t ors, int rows, int cols, const dcmt_stereo_params* params)
+{
+    if (!ctx || !depth || !left || !right || !refined || !params || rows < 1 || cols < 1) return DCMT_E_INVALID;
+    if (drs < sizeof(float) * (size_t)cols || ors < sizeof(float) * (size_t)cols || lrs < (size_t)cols || rrs < (size_t)cols) return DCMT_E_INVALID;
+    hipStream_t st;
+    int rc = host_stream(ctx, &st);
+    if (rc != DCMT_OK) return rc;
+    DevBuf dd, dl, dr, dout;
+    const size_t frow = sizeof(float) * (size_t)cols, brow = (size_t)cols;
+    if ((rc = dd.alloc(ctx, frow * rows)) != DCMT_OK || (rc = dl.alloc(ctx, brow * rows)) != DCMT_OK || (rc = dr.alloc(ctx, brow * rows)) != DCMT_OK ||
+        (rc = dout.alloc(ctx, frow * rows)) != DCMT_OK) return rc;
+    DCMT_HIP(ctx, hipMemcpy2DAsync(dd.p, frow, depth, drs, frow, rows, hipMemcpyHostToDevice, st));
+    DCMT_HIP(ctx, hipMemcpy2DAsync(dl.p, brow, left, lrs, brow, rows, hipMemcpyHostToDevice, st));
+    DCMT_HIP(ctx, hipMemcpy2DAsync(dr.p, brow, right, rrs, brow, rows, hipMemcpyHostToDevice, st));
+    rc = dcmt_stereo_refine_dev(ctx, (const float*)dd.p, (const uint8_t*)dl.p, (const uint8_t*)dr.p, (float*)dout.p, rows, cols, 1, params, st);
+    if (rc != DCMT_OK) return rc;
+    DCMT_HIP(ctx, hipMemcpy2DAsync(refined, ors, dout.p, frow, frow, rows, hipMemcpyDeviceToHost, st));
+    DCMT_HIP(ctx, hipStreamSynchronize(st));
+    return DCMT_OK;
+}
+
 static int read_counters(dcmt_ctx* ctx)
 {
     DCMT_HIP(ctx, hipSetDevice(ctx->device));

@@ -230,6 +230,20 @@ int dcmt_stereo_refine_dev(dcmt_ctx *ctx, const float *d_depth, const uint8_t *d
                            float *d_refined, int rows, int cols, int batch, const dcmt_stereo_params *params,
                            void *stream);
 
+/* ---- the same three on HOST memory (one frame, synchronous): what the cv::Mat shim calls ---------------- */
+
+/* Each copies its inputs to the device, runs the device entry point above and copies the result back; device buffers
+ * are allocated for the call and freed again (these calls are bound by the PCIe copies, not by that).
+ * Row strides in BYTES (cv::Mat::step); labels / centres / points are contiguous. */
+int dcmt_project_points(dcmt_ctx *ctx, const float *points, int n_points, const float T[16], const float P[12],
+                        float *sparse, size_t sparse_row_stride, int rows, int cols);
+int dcmt_slic_labels(dcmt_ctx *ctx, const uint8_t *lab, size_t lab_row_stride, int rows, int cols, int step, int nc,
+                     int32_t *labels /* [rows][cols] */, double *centers /* [n][5] or NULL */);
+int dcmt_stereo_refine(dcmt_ctx *ctx, const float *depth, size_t depth_row_stride,
+                       const uint8_t *left, size_t left_row_stride, const uint8_t *right, size_t right_row_stride,
+                       float *refined, size_t refined_row_stride, int rows, int cols,
+                       const dcmt_stereo_params *params);
+
 /* ---- probes ------------------------------------------------------------------------ */
 
 /* Per frame of the last call on ctx: the number of iterations the reference's while-loop

@@ -132,6 +132,53 @@ inline void img_completion_normalized(const cv::Mat& projected, cv::Mat& dense_r
     dense_r_img = out;
 }
 
+// ---- the steps either side of the path, on cv::Mat / std::vector like the reference's own code -----------------------
+
+// DC_stereo_lidar/main_sl.cpp:478-520: velodyne points ([n][4] floats: x, y, z, reflectance, the .bin payload) through
+// T (4x4) and P (3x4), both ROW-major, into a fresh CV_32FC1 image of rows x cols (0 = no point), like projected_depths.
+inline void project_points(const float* xyzi, int n_points, const float T[16], const float P[12], int rows, int cols,
+                           cv::Mat& projected_depths)
+{
+    cv::Mat out;
+    out.create(rows, cols, CV_32FC1);
+    raise(dcmt_project_points(thread_ctx().get(rows, cols), xyzi, n_points, T, P, out.ptr<float>(), out.step[0], rows, cols),
+          "project_points");
+    projected_depths = out;
+}
+
+// Slic::generate_superpixels (DC_lidar_camera/slic.cpp:101-182) on the CV_8UC3 image the reference passes; fills `clusters`
+// as Slic::clusters ([col][row]) and returns slic.centers.size().
+inline int slic_labels(const cv::Mat& lab_image, int step, int nc, std::vector<std::vector<int> >& clusters)
+{
+    if (lab_image.type() != CV_8UC3 || lab_image.rows < 1 || lab_image.cols < 1) throw std::runtime_error("slic_labels: image must be CV_8UC3");
+    const int rows = lab_image.rows, cols = lab_image.cols;
+    std::vector<int32_t> lab((size_t)rows * cols);
+    raise(dcmt_slic_labels(thread_ctx().get(rows, cols), lab_image.ptr<unsigned char>(), lab_image.step[0], rows, cols, step, nc,
+                           lab.data(), nullptr), "slic_labels");
+    clusters.assign(cols, std::vector<int>(rows));
+    for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < rows; ++i) clusters[j][i] = lab[(size_t)i * cols + j];
+    return dcmt_slic_num_centers(rows, cols, step);
+}
+
+// DC_stereo_lidar/main_sl.cpp:1165-1246: get_initial_disparity + calculateMeasuementDerivatives + optimize_IG +
+// retrieve_optimized_depth on the dense depth (CV_32FC1) and the two grey images (CV_8UC1).
+inline void stereo_refine(const cv::Mat& dense_depth, const cv::Mat& left_gray, const cv::Mat& right_gray, cv::Mat& optimized_depth)
+{
+    check_input(dense_depth);
+    const int rows = dense_depth.rows, cols = dense_depth.cols;
+    if (left_gray.type() != CV_8UC1 || right_gray.type() != CV_8UC1 || left_gray.rows != rows || right_gray.rows != rows ||
+        left_gray.cols != cols || right_gray.cols != cols) throw std::runtime_error("stereo_refine: grey images must be CV_8UC1 of the depth's size");
+    cv::Mat out;
+    out.create(rows, cols, CV_32FC1);
+    dcmt_stereo_params sp;
+    dcmt_default_stereo_params(&sp);
+    raise(dcmt_stereo_refine(thread_ctx().get(rows, cols), dense_depth.ptr<float>(), dense_depth.step[0], left_gray.ptr<unsigned char>(),
+                             left_gray.step[0], right_gray.ptr<unsigned char>(), right_gray.step[0], out.ptr<float>(), out.step[0], rows, cols, &sp),
+          "stereo_refine");
+    optimized_depth = out;
+}
+
 }  // namespace dcmt_shim
 
 // reference: src/DC_lidar_only/img_completion.cpp:17-20.  `extr` is accepted and ignored, as there.

@@ -8,6 +8,7 @@
 
 #define CV_32FC1 5
 #define CV_8UC1 0
+#define CV_8UC3 16
 
 namespace cv {
 class Mat {
@@ -36,7 +37,7 @@ public:
     template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
     template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
 private:
-    size_t elem() const { return type_ == CV_32FC1 ? 4 : 1; }
+    size_t elem() const { return type_ == CV_32FC1 ? 4 : (type_ == CV_8UC3 ? 3 : 1); }
     int type_ = CV_32FC1;
     std::shared_ptr<unsigned char> buf_;     // ref-counted like cv::Mat
     unsigned char* data_ = nullptr;

@@ -72,6 +72,37 @@ int main(int argc, char** argv)
             if (!write_all(argv[9], out.data(), out.size() * 4)) return 11;
         }
     }
+    if (argc >= 17) {
+        // the steps either side of the path through the shim: argv[10] points.f32 [n][4], argv[11] n, argv[12] out_proj.f32 (T, P = the
+        // KITTI-like constants below); argv[13] lab.u8 [rows][cols][3] -> argv[14] out_labels.i32; argv[15] right.u8 (left = channel-free
+        // copy of lab's first plane is not available here: the driver writes left.u8 next to it as argv[15] + ".left") -> argv[16] out_stereo.f32
+        const int n_pts = std::atoi(argv[11]);
+        std::vector<float> pts((size_t)n_pts * 4);
+        if (!read_all(argv[10], pts.data(), pts.size() * 4)) return 12;
+        const float T[16] = {7.533745e-03f, -9.999714e-01f, -6.166020e-04f, -4.069766e-03f, 1.480249e-02f, 7.280733e-04f, -9.998902e-01f, -7.631618e-02f,
+                             9.998621e-01f, 7.523790e-03f, 1.480755e-02f, -2.717806e-01f, 0.f, 0.f, 0.f, 1.f};
+        const float P[12] = {7.215377e+02f, 0.f, 6.095593e+02f, 4.485728e+01f, 0.f, 7.215377e+02f, 1.728540e+02f, 2.163791e-01f, 0.f, 0.f, 1.f, 2.745884e-03f};
+        cv::Mat proj;
+        dcmt_shim::project_points(pts.data(), n_pts, T, P, rows, cols, proj);
+        for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], proj.ptr<float>(r), (size_t)cols * 4);
+        if (!write_all(argv[12], out.data(), out.size() * 4)) return 13;
+
+        cv::Mat lab_img(rows, cols, CV_8UC3);
+        if (!read_all(argv[13], lab_img.ptr<unsigned char>(), (size_t)rows * cols * 3)) return 14;
+        std::vector<std::vector<int> > cl;
+        const int n_centers = dcmt_shim::slic_labels(lab_img, 18, 50, cl);
+        std::vector<int32_t> lab_out((size_t)rows * cols);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) lab_out[(size_t)r * cols + c] = cl[c][r];
+        if (n_centers <= 0 || !write_all(argv[14], lab_out.data(), lab_out.size() * 4)) return 15;
+
+        cv::Mat lg(rows, cols, CV_8UC1), rg(rows, cols, CV_8UC1), refined;
+        const std::string left_path = std::string(argv[15]) + ".left";
+        if (!read_all(left_path.c_str(), lg.ptr<unsigned char>(), (size_t)rows * cols) || !read_all(argv[15], rg.ptr<unsigned char>(), (size_t)rows * cols)) return 16;
+        dcmt_shim::stereo_refine(dense, lg, rg, refined);
+        for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], refined.ptr<float>(r), (size_t)cols * 4);
+        if (!write_all(argv[16], out.data(), out.size() * 4)) return 17;
+    }
     std::printf("shim ok\n");
     return 0;
 }

@@ -23,11 +23,20 @@ def test_cpp_caller_matches_oracle(tmp_path):
     rows, cols = 352, 1216
     x = synth.synth_frame(rows, cols, 4)
     lab, nl = synth.synth_labels(rows, cols, 1200, 4)
+    pts = synth.synth_points(60000, 4)
+    pts.tofile(tmp_path / "pts.f32")
+    lab_img = synth.synth_lab(rows, cols, 4)
+    lab_img.tofile(tmp_path / "lab.u8")
+    lg, rg, _ = synth.synth_stereo(rows, cols, 4)
+    rg.tofile(tmp_path / "right.u8")
+    lg.tofile(tmp_path / "right.u8.left")
     x.tofile(tmp_path / "in.f32")
     lab.tofile(tmp_path / "lab.i32")
     r = subprocess.run([os.path.join(ROOT, "tests", "mock_opencv", "shim_test"), str(rows), str(cols), str(tmp_path / "in.f32"),
                         str(tmp_path / "out.f32"), str(tmp_path / "lab.i32"), str(nl), str(tmp_path / "out_lc.f32"),
-                        str(tmp_path / "out_n100.f32"), str(tmp_path / "out_lc_n80.f32")],
+                        str(tmp_path / "out_n100.f32"), str(tmp_path / "out_lc_n80.f32"),
+                        str(tmp_path / "pts.f32"), str(len(pts)), str(tmp_path / "out_proj.f32"),
+                        str(tmp_path / "lab.u8"), str(tmp_path / "out_slic.i32"), str(tmp_path / "right.u8"), str(tmp_path / "out_stereo.f32")],
                        capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "NUMERO ROWS, COLS: 352 1216" in r.stdout          # the reference prints this (img_completion.cpp:29)
@@ -39,3 +48,10 @@ def test_cpp_caller_matches_oracle(tmp_path):
     assert_bit_equal(got_n, O.img_completion(O.normalize_minmax(x, 0, 100)), "C++ normalize + img_completion")
     got_n = np.fromfile(tmp_path / "out_lc_n80.f32", dtype=np.float32).reshape(rows, cols)
     assert_bit_equal(got_n, O.interpolate_with_superpixels(O.normalize_minmax(x, 0, 80), lab, nl), "C++ normalize + interpolate_with_superpixels")
+    # the steps either side of the path, through the shim's cv::Mat / std::vector forms (host entry points of the C ABI)
+    got_p = np.fromfile(tmp_path / "out_proj.f32", dtype=np.float32).reshape(rows, cols)
+    assert_bit_equal(got_p, O.project_points(pts, synth.KITTI_T_VELO_TO_CAM, synth.KITTI_P2, rows, cols), "C++ project_points")
+    got_s = np.fromfile(tmp_path / "out_slic.i32", dtype=np.int32).reshape(rows, cols)
+    assert np.array_equal(got_s, O.slic(lab_img, 18, 50)[0])
+    got_r = np.fromfile(tmp_path / "out_stereo.f32", dtype=np.float32).reshape(rows, cols)
+    assert_bit_equal(got_r, O.stereo_refine(got, lg, rg), "C++ stereo_refine on the completed depth")
