@@ -231,9 +231,9 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     float XR[8];                                 // diamond only: x2 rows
     float A3[8];                                 // diamond only: horizontal 3-max rows
     float S1[8];                                 // as-compiled only: x2 shifted by one column
-    float H4[8], HE[8], H7[8], E4[8];
+    float H4[8], HE[8], H7[8], E4[8], T7[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; H7[q] = NEG; E4[q] = NEG; PF[q] = 0.f; }
+    for (int q = 0; q < 8; ++q) { XR[q] = NEG; A3[q] = NEG; S1[q] = NEG; H4[q] = NEG; HE[q] = POS; H7[q] = NEG; E4[q] = NEG; T7[q] = NEG; PF[q] = 0.f; }
 
 #ifndef DCMT_PRE_PFD
 #define DCMT_PRE_PFD 4
@@ -303,9 +303,10 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // ---- H5 (LO :88-100): dilate 7x7, row m = l - 3, then fill where x < 0.1
             H7[(p + 2) & 7] = hgrow_max(hgrow_max(hmax3(e4)));
             const int m = i - 9;
-            const float d7 = fmax2(fmax3(fmax3(H7[(p + 4) & 7], H7[(p + 5) & 7], H7[(p + 6) & 7]),
-                                         H7[(p + 7) & 7], H7[(p + 0) & 7]),
-                                   fmax2(H7[(p + 1) & 7], H7[(p + 2) & 7]));   // rows m-3 .. m+3 = i-12 .. i-6
+            // vertical 7-max over rows m-3 .. m+3 = i-12 .. i-6 in two three-input instructions: the maximum of the three
+            // newest rows is kept per step, so the window is (this step's triple, the triple of three steps ago, row i-12)
+            T7[p] = fmax3(H7[(p + 0) & 7], H7[(p + 1) & 7], H7[(p + 2) & 7]);      // rows i-8 .. i-6
+            const float d7 = fmax3(T7[p], T7[(p + 5) & 7] /* rows i-11 .. i-9 */, H7[(p + 4) & 7] /* row i-12 */);
             const float e = E4[(p + 7) & 7];                             // row m = i-9
             const float x5 = e < thr ? d7 : e;
             if ((unsigned)m < (unsigned)rows) {
