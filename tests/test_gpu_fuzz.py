@@ -75,3 +75,65 @@ def test_fuzz_against_oracle(seed):
             src = frames[f] if norm is None else O.normalize_minmax(frames[f], *norm)
             ref = O.interpolate_with_superpixels(src, lab, n, op) if labeled else O.img_completion(src, op)
             assert_bit_equal(got[f], ref, what + f" frame {f}")
+
+
+def test_mixed_calls_on_one_context_keep_no_state():
+    """One long-lived context, forty calls of every kind in random order and random sizes (host and device entry points, labels,
+    normalise, uint16 ingest, projection, SLIC, stereo refinement): scratch reuse, table regrowth and leftovers of an earlier
+    call must never leak into a later result."""
+    import torch
+    from oracle import oracle as O
+    from depth_completion_mt_amd import synth
+    g = np.random.Generator(np.random.PCG64(77))
+    with api.Context(0, 160, 320, 13) as c:
+        for call in range(40):
+            kind = int(g.integers(0, 7))
+            rows, cols = int(g.integers(16, 160)), int(g.integers(16, 320))
+            what = f"call {call} kind {kind} {rows}x{cols}"
+            if kind == 0:                                            # host entry, small batch (staged path)
+                b = int(g.integers(1, 4))
+                x = np.stack([_frame(g, rows, cols) for _ in range(b)])
+                got = c.complete(x, api.make_params(max_fill_iters=6), allow_not_converged=True)
+                for f in range(b):
+                    assert_bit_equal(got[f], O.img_completion(x[f], O.default_params(max_fill_iters=6)), what)
+            elif kind == 1:                                          # device entry, batch 13 (streaming path), normalise on/off
+                x = np.stack([_frame(g, rows, cols) for _ in range(13)])
+                norm = (None, (0, 80))[g.integers(0, 2)]
+                out = c.complete_dev(torch.from_numpy(x).cuda(), params=api.make_params(normalize=norm, spec_fill_iters=5, max_fill_iters=6))
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                for f in (0, 12):
+                    src = x[f] if norm is None else O.normalize_minmax(x[f], *norm)
+                    assert_bit_equal(got[f], O.img_completion(src, O.default_params(max_fill_iters=6)), what)
+            elif kind == 2:                                          # labeled, host
+                x = _frame(g, rows, cols)
+                lab, n = _labels(g, rows, cols)
+                got = c.complete(x, api.make_params(max_fill_iters=6, force_fused=bool(g.integers(0, 2))), labels=lab, n_labels=n, allow_not_converged=True)
+                assert_bit_equal(got, O.interpolate_with_superpixels(x, lab, n, O.default_params(max_fill_iters=6)), what)
+            elif kind == 3:                                          # uint16 ingest, batch 13
+                u16 = (np.stack([_frame(g, rows, cols) for _ in range(13)]) * 256).astype(np.uint16)
+                out = c.complete_u16_dev(torch.from_numpy(u16.view(np.int16)).cuda(), 1.0 / 256.0, params=api.make_params(spec_fill_iters=5, max_fill_iters=6))
+                torch.cuda.synchronize()
+                f32 = (u16.astype(np.float32) * np.float32(1.0 / 256.0)).astype(np.float32)
+                assert_bit_equal(out.cpu().numpy()[5], O.img_completion(f32[5], O.default_params(max_fill_iters=6)), what)
+            elif kind == 4:                                          # projection
+                pts = synth.synth_points(int(g.integers(0, 5000)), int(g.integers(0, 1000)))
+                P = np.array([[60.0, 0, cols / 2, 3.0], [0, 60.0, rows / 2, 0.01], [0, 0, 1, 0.002]], np.float32)
+                off = torch.tensor([0, len(pts)], dtype=torch.int32, device="cuda")
+                out = c.project_points_dev(torch.from_numpy(pts).cuda(), off, synth.KITTI_T_VELO_TO_CAM, P, rows, cols)
+                torch.cuda.synchronize()
+                assert_bit_equal(out.cpu().numpy()[0], O.project_points(pts, synth.KITTI_T_VELO_TO_CAM, P, rows, cols), what)
+            elif kind == 5:                                          # SLIC
+                step = int(g.integers(6, 30))
+                if rows <= 2 * step or cols <= 2 * step:
+                    continue
+                img = synth.synth_lab(rows, cols, int(g.integers(0, 1000)))
+                lab, n = c.slic_labels_dev(torch.from_numpy(img).cuda(), step, int(g.integers(5, 60)) if False else 40)
+                torch.cuda.synchronize()
+                wl, wn = O.slic(img, step, 40)
+                assert n == wn and np.array_equal(lab.cpu().numpy()[0], wl), what
+            else:                                                    # stereo refinement
+                l, r, d = synth.synth_stereo(rows, cols, int(g.integers(0, 1000)), focal=80.0)
+                out = c.stereo_refine_dev(torch.from_numpy(d).cuda(), torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), focal=80.0)
+                torch.cuda.synchronize()
+                assert_bit_equal(out.cpu().numpy(), O.stereo_refine(d, l, r, focal=80.0), what)
