@@ -1013,7 +1013,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             }
         }
         if (edge_strip) x7 = __shfl(x7, src_lane, 64);             // out-of-image columns replicate the edge column
-        if (o >= rows) x7 = x7_prev;                                // rows below the image replicate the last row (median border)
+        if (o >= rows) { asm volatile("" ::); x7 = x7_prev; }       // rows below the image replicate the last row (median border); the
+                                                                    // empty asm keeps this a scalar branch (last 7 steps only) instead of a select per step
         x7_prev = x7;
         // vertical 31-max, both registers (see k_fill_s)
         const float w2a = fmax2(xa, vpa), w2b = fmax2(xb, vpb);
