@@ -213,6 +213,42 @@ def main():
             extra["batch1_streamed_frames_per_s" if nstreams == 1 else f"batch1_streamed_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
             for c in ctxs:
                 c.close()
+        # BASELINE configs[1] as SURVEY.md section 8d words it: host-pinned input and output, frames arriving one at a time --
+        # per frame an H2D copy, the cascade on that one frame, a D2H copy, all stream-ordered; four streams keep the PCIe
+        # copies of one frame under the kernels of another
+        for nstreams in (1, 4):
+            ctxs = [Context(local_rank, ROWS, COLS, 1) for _ in range(nstreams)]
+            streams = [torch.cuda.Stream() for _ in range(nstreams)]
+            h_in = [torch.from_numpy(host[i % uniq]).pin_memory() for i in range(nstreams)]
+            h_out = [torch.empty((ROWS, COLS), dtype=torch.float32).pin_memory() for _ in range(nstreams)]
+            dv_in = [torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda") for _ in range(nstreams)]
+            dv_out = [torch.empty_like(dv_in[0]) for _ in range(nstreams)]
+            def run_pinned(n):
+                for i in range(n):
+                    k = i % nstreams
+                    with torch.cuda.stream(streams[k]):
+                        dv_in[k].copy_(h_in[k], non_blocking=True)
+                        ctxs[k].complete_dev(dv_in[k], dv_out[k], params, stream=streams[k].cuda_stream)
+                        h_out[k].copy_(dv_out[k], non_blocking=True)
+            run_pinned(4 * nstreams)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_pinned(n1)
+            torch.cuda.synchronize()
+            extra["batch1_host_pinned_frames_per_s" if nstreams == 1 else f"batch1_host_pinned_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
+            for c in ctxs:
+                c.close()
+        # and the drop-in itself: dcmt_complete_f32 on pageable host arrays, one synchronous call per frame -- what the
+        # cv::Mat shim does for the reference's own mains
+        hctx = Context(local_rank, ROWS, COLS, 1)
+        hp = make_params()
+        for i in range(8):
+            hctx.complete(host[i % uniq], hp)
+        t1 = time.perf_counter()
+        for i in range(n1):
+            hctx.complete(host[i % uniq], hp)
+        extra["batch1_host_api_frames_per_s"] = n1 / (time.perf_counter() - t1)
+        hctx.close()
         # the same single-frame call captured once into a HIP graph and replayed: the entry point never synchronises or
         # allocates, so its memsets and kernel launches are capturable as they are; the replay removes the per-launch host cost
         gctx = Context(local_rank, ROWS, COLS, 1)
