@@ -442,6 +442,9 @@ int host_call(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int
     const size_t row_b = sizeof(float) * (size_t)cols, frame_b = row_b * rows;
     if (p->verbose) std::printf("NUMERO ROWS, COLS: %d %d\n", rows, cols);   // LO :29
     for (int f = 0; f < batch; ++f) {
+        if (srs == row_b)      // contiguous rows (the usual cv::Mat): one linear copy instead of a pitched one
+            DCMT_HIP(ctx, hipMemcpyAsync((char*)ctx->d_in + f * frame_b, (const char*)src + f * sfs, frame_b, hipMemcpyHostToDevice, st));
+        else
         DCMT_HIP(ctx, hipMemcpy2DAsync((char*)ctx->d_in + f * frame_b, row_b, (const char*)src + f * sfs, srs, row_b, rows,
                                        hipMemcpyHostToDevice, st));
         if (labels)
@@ -453,9 +456,13 @@ int host_call(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int
     const int chain_rc = run_chain(ctx, ctx->d_in, labels ? ctx->d_lab : nullptr, n_labels, use_superpixel, ctx->d_out,
                                    rows, cols, batch, p, force_gaussian, st, true);
     if (chain_rc != DCMT_OK && chain_rc != DCMT_E_NOT_CONVERGED) return chain_rc;
-    for (int f = 0; f < batch; ++f)
-        DCMT_HIP(ctx, hipMemcpy2DAsync((char*)dst + f * dfs, drs, (const char*)ctx->d_out + f * frame_b, row_b, row_b, rows,
-                                       hipMemcpyDeviceToHost, st));
+    for (int f = 0; f < batch; ++f) {
+        if (drs == row_b)
+            DCMT_HIP(ctx, hipMemcpyAsync((char*)dst + f * dfs, (const char*)ctx->d_out + f * frame_b, frame_b, hipMemcpyDeviceToHost, st));
+        else
+            DCMT_HIP(ctx, hipMemcpy2DAsync((char*)dst + f * dfs, drs, (const char*)ctx->d_out + f * frame_b, row_b, row_b, rows,
+                                           hipMemcpyDeviceToHost, st));
+    }
     DCMT_HIP(ctx, hipStreamSynchronize(st));
     return chain_rc;
 }
