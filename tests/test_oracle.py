@@ -317,3 +317,19 @@ def test_primitives_match_scipy_ndimage():
     assert_bit_equal(O.dilate_mask5(x, k0), want, "first element, un-reflected")
     kd = O.k0_diamond()
     assert_bit_equal(O.dilate_mask5(x, kd), ndi.grey_dilation(x, footprint=kd.astype(bool), mode="constant", cval=-fmax), "diamond")
+
+
+def test_generated_median_networks_are_reproducible_and_proven(tmp_path):
+    """tools/median_shared_nets3.h is exactly what tools/gen_median_3in.py generates (the generator re-proves every rewrite
+    with the 0/1 principle on sorted inputs and cross-checks random floats while it runs), and the closing five-med3
+    chain selects the 6th smallest of sorted 6 + sorted 5."""
+    import importlib.util, os, shutil
+    from conftest import ROOT
+    src = os.path.join(ROOT, "tools")
+    for f in ("gen_median_3in.py", "median_shared_nets.h"):
+        shutil.copy(os.path.join(src, f), tmp_path / f)
+    spec = importlib.util.spec_from_file_location("gen3", str(tmp_path / "gen_median_3in.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    g.main()                                          # asserts inside: 0/1 proof + 20000 random merges per network + the final chain
+    assert open(tmp_path / "median_shared_nets3.h").read() == open(os.path.join(src, "median_shared_nets3.h")).read()
