@@ -549,9 +549,9 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
 //
 // The exact median is time-shared down the column (tools/gen_median_shared.py has the scheme
 // and its verification): every row's 5 horizontal neighbours are sorted once (12 three-input
-// instructions), every second row a pair of sorted rows is merged (20) and the six middle order
-// statistics of the 4-row core are extracted (25); each window's median is then the 6th smallest of
-// those six and the sorted fifth row (5).  42.5 instructions per pixel instead of ~200
+// instructions), every second row a pair of sorted rows is merged (19) and the six middle order
+// statistics of the 4-row core are extracted (24); each window's median is then the 6th smallest of
+// those six and the sorted fifth row (5).  38.5 instructions per pixel instead of ~200
 // (tools/gen_median_3in.py has the three-input rewriting of the networks and its proof).
 // ---------------------------------------------------------------------------------
 struct PostS {
@@ -578,7 +578,7 @@ __device__ __forceinline__ void sort5(float (&v)[5])
 }
 // The two merge networks in their three-input form (tools/gen_median_3in.py: the exchange networks of
 // median_shared_nets.h rewritten with min3 / max3 / med3 using the order knowledge of their sorted inputs, each
-// rewrite proven by the 0/1 principle on sorted inputs): 20 instead of 26 and 25 instead of 36 instructions.
+// rewrite proven by the 0/1 principle on sorted inputs): 19 instead of 26 and 24 instead of 36 instructions.
 // P = merge of two sorted 5-lists
 __device__ __forceinline__ void merge55(const float (&a)[5], const float (&b)[5], float (&P)[10])
 {

@@ -10,7 +10,7 @@ the right order statistics.  min, max and med3 all commute with monotone maps, s
 built from them: checking every pair of SORTED 0/1 input lists (the input class is closed under monotone maps) proves the
 rewritten network for all inputs, ties included.  A random-float cross-check against sorted() runs as well.
 
-MERGE55: 26 -> 20 instructions.  MID20: 36 -> 25.  (Per pair of image rows: 62 -> 45.)  The closing selection (the
+MERGE55: 26 -> 19 instructions.  MID20: 36 -> 24.  (Per pair of image rows: 62 -> 43.)  The closing selection (the
 6th smallest of the six core statistics and the sorted fifth row) becomes a chain of five med3 by the same argument
 (check_final below; the kernel writes it out by hand): 8 -> 5 per row.
 """
@@ -69,7 +69,10 @@ def prune(tr, outs):
         prev = len(tr); uu = uses(tr, outs); tr = [t for t in tr if uu.get(t[1], 0) > 0]
     return tr
 
-def optimise(ops, outs, na, nb):
+def optimise(ops, outs, na, nb, seed=None):
+    """Greedy rewriting; the order in which producers and replacement kinds are tried is shuffled by `seed` (None: network
+    order).  Different orders end in different local minima: SEEDS below are the best of a 400-seed search per network."""
+    rnd = random.Random(seed)
     ref = [run(ops, outs, p) for p in patterns(na, nb)]
     changed = True
     while changed:
@@ -79,12 +82,16 @@ def optimise(ops, outs, na, nb):
         for o in ops:
             for s in o[2]:
                 if s[0] == "op": cons.setdefault(s[1], []).append(o[1])
-        for T in ops:
+        order = list(ops)
+        if seed is not None: rnd.shuffle(order)
+        for T in order:
             if T[0] not in ("min", "max") or len(T[2]) != 2: continue
             cs = cons.get(T[1], [])
             if not 1 <= len(cs) <= 2 or uses(ops, outs).get(T[1], 0) >= 100: continue
             if any(byid[c][0] not in ("min", "max") or len(byid[c][2]) != 2 for c in cs): continue
-            for combo in itertools.product(("med3", "min3", "max3"), repeat=len(cs)):
+            combos = list(itertools.product(("med3", "min3", "max3"), repeat=len(cs)))
+            if seed is not None: rnd.shuffle(combos)
+            for combo in combos:
                 trial = [[k, j, list(ss)] for k, j, ss in ops]
                 tb = {t[1]: t for t in trial}
                 ok = True
@@ -129,6 +136,8 @@ def check_final():
         assert chain(c, a) == sorted(c + a)[5]
     print("FINAL 8 -> 5 (med3 chain)")
 
+SEEDS = {"MERGE55": 12, "MID20": 11}        # 19 and 24 instructions (network order gives 20 and 25; 400 seeds found nothing smaller)
+
 def main():
     check_final()
     hdr = ["/* GENERATED by tools/gen_median_3in.py -- do not edit.  The MERGE55 and MID20 networks of median_shared_nets.h",
@@ -139,7 +148,7 @@ def main():
         body, outw = read_net(name)
         ops, wire = parse(body, na + nb)
         outs = [wire[w] for w in outw]
-        new = optimise(ops, outs, na, nb)
+        new = optimise(ops, outs, na, nb, SEEDS[name])
         # random floats with ties against sorted()
         rnd = random.Random(1)
         want_ranks = list(range(10)) if name == "MERGE55" else list(range(7, 13))
