@@ -23,8 +23,6 @@
 #include <type_traits>
 
 #include "dcmt_kernels_v1.h"
-#include "median_shared_nets.h"
-#include "median_shared_nets3.h"
 
 namespace dcmt {
 
@@ -38,8 +36,6 @@ __device__ __forceinline__ float from_right(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float fmax3(float a, float b, float c) { return fmax2(fmax2(a, b), c); }   // -> v_max3_f32
-__device__ __forceinline__ float fmin3(float a, float b, float c) { return fmin2(fmin2(a, b), c); }   // -> v_min3_f32
 
 // horizontal windows over lanes: 3 = [c-1,c+1], 5 = [c-2,c+2], 7 = [c-3,c+3]
 __device__ __forceinline__ float hmax3(float v) { const float a = fmax2(from_left(v), v); return fmax2(from_right(a), a); }
@@ -77,15 +73,6 @@ struct FrameBuf {
     }
 };
 
-// compile-time loop: f(std::integral_constant<int, P>) for P in [B, E)
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 
 __device__ __forceinline__ int wave_max_i(int v)
 {
@@ -558,60 +545,6 @@ struct PostS {
     static constexpr int H = 4;                  // 2 (median) + 2 (Gaussian) lanes lost per side
     static constexpr int VW = 64 - 2 * H;
 };
-
-#define DCMT_CX(a, b)   { const float lo_ = fmin2(v[a], v[b]); v[b] = fmax2(v[a], v[b]); v[a] = lo_; }
-#define DCMT_CMIN(a, b) { v[a] = fmin2(v[a], v[b]); }
-#define DCMT_CMAX(a, b) { v[b] = fmax2(v[a], v[b]); }
-// sort5 in 12 three-input instructions instead of a 9-exchange network's 18 (min/max/med3 all issue
-// at the same rate): sort a triple (min3, med3, max3) and a pair, then merge them in closed form.
-// Verified against sorted() on all 5^5 value patterns (ties included).
-__device__ __forceinline__ void sort5(float (&v)[5])
-{
-    const float x0 = fmin3(v[0], v[1], v[2]), x1 = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]), x2 = fmax3(v[0], v[1], v[2]);
-    const float y0 = fmin2(v[3], v[4]), y1 = fmax2(v[3], v[4]);
-    const float A = fmax2(x0, y0), B = fmin2(x2, y1);
-    v[0] = fmin2(x0, y0);
-    v[1] = fmin3(A, x1, y1);
-    v[2] = __builtin_amdgcn_fmed3f(A, x1, B);
-    v[3] = fmax3(B, x1, y0);
-    v[4] = fmax2(x2, y1);
-}
-// The two merge networks in their three-input form (tools/gen_median_3in.py: the exchange networks of
-// median_shared_nets.h rewritten with min3 / max3 / med3 using the order knowledge of their sorted inputs, each
-// rewrite proven by the 0/1 principle on sorted inputs): 19 instead of 26 and 24 instead of 36 instructions.
-// P = merge of two sorted 5-lists
-__device__ __forceinline__ void merge55(const float (&a)[5], const float (&b)[5], float (&P)[10])
-{
-#define DCMT_IN(k) ((k) < 5 ? a[(k) < 5 ? (k) : 0] : b[(k) >= 5 ? (k) - 5 : 0])
-#define DCMT_OUT(k) P[k]
-    DCMT_MERGE55_3IN(DCMT_IN, DCMT_OUT)
-#undef DCMT_IN
-#undef DCMT_OUT
-}
-// C = ranks 8..13 (1-based, ascending) of the union of two sorted 10-lists
-__device__ __forceinline__ void mid20(const float (&pa)[10], const float (&pb)[10], float (&C)[6])
-{
-#define DCMT_IN(k) ((k) < 10 ? pa[(k) < 10 ? (k) : 0] : pb[(k) >= 10 ? (k) - 10 : 0])
-#define DCMT_OUT(k) C[k]
-    DCMT_MID20_3IN(DCMT_IN, DCMT_OUT)
-#undef DCMT_IN
-#undef DCMT_OUT
-}
-#undef DCMT_CX
-#undef DCMT_CMIN
-#undef DCMT_CMAX
-// 6th smallest of sorted C (6) u sorted a (5) = the median of the 25-window:
-//     min(C5, max(a0,C4), max(a1,C3), max(a2,C2), max(a3,C1), max(a4,C0))
-// folded into five med3: with r >= min(a_i, C_{4-i}) -- which the sortedness of C and a guarantees at every step --
-// min(r, max(a_i, C_{4-i})) = med3(a_i, C_{4-i}, r).  Checked on all sorted 0/1 inputs (min / max / med3 commute with
-// monotone maps, so that proves it for all inputs) and on random floats with ties (tools/gen_median_3in.py).
-__device__ __forceinline__ float final6(const float (&C)[6], const float (&a)[5])
-{
-    float r = C[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r = __builtin_amdgcn_fmed3f(a[i], C[4 - i], r);
-    return r;
-}
 
 // One pass of the [1 4 6 4 1]/16 filter in the reference order  c*k0 + s1*k1 + s2*k2  (s1, s2 = the already rounded
 // sums of the two neighbour pairs; every product rounded, the sum taken left to right).  k1 = 1/4 and k2 = 1/16 are

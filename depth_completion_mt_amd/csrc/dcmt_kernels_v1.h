@@ -23,7 +23,7 @@
 #include <float.h>
 #include <stdint.h>
 
-#include "median_net25.h"
+#include "dcmt_median.h"
 
 namespace dcmt {
 
@@ -36,8 +36,6 @@ constexpr int kCntStride = kMaxIters + 4;  // ints per frame in the counter bloc
 //  [1 + k]        holes left after fill application k (k = 0 is H7 itself, k >= 1 the loop)
 __device__ __forceinline__ int* frame_counters(int* counters, int f) { return counters + (size_t)f * kCntStride; }
 
-__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
-__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_fminf(a, b); }
 
 // for every (y,x) in [y0,y1) x [x0,x1), consecutive threads on consecutive x
 template <typename F>
@@ -658,18 +656,6 @@ void k_fill31_v1(const float* __restrict__ in, float* __restrict__ out, const in
 //            the frame after its last fill application.
 // mode: 8 = copy only (probe of H8), 9 = stop after the median, 10 = after the blur, 11 = all
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ float median25(float (&v)[25])
-{
-#define DCMT_CX(a, b)   { const float lo = fmin2(v[a], v[b]); v[b] = fmax2(v[a], v[b]); v[a] = lo; }
-#define DCMT_CMIN(a, b) { v[a] = fmin2(v[a], v[b]); }
-#define DCMT_CMAX(a, b) { v[b] = fmax2(v[a], v[b]); }
-    DCMT_MED25_NET(DCMT_CX, DCMT_CMIN, DCMT_CMAX)
-#undef DCMT_CX
-#undef DCMT_CMIN
-#undef DCMT_CMAX
-    return v[12];
-}
-
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1) return 0;
@@ -715,17 +701,29 @@ void k_post_v1(const float* __restrict__ pp0, const float* __restrict__ pp1, flo
         A[y * P + x] = xin[(size_t)gy * cols + gx];
     });
     __syncthreads();
-    // H9 on every in-image pixel of tile +- 2
-    for_rect(2, RH - 2, 2, RW - 2, [&](int y, int x) {
-        const int gy = ty0 + y, gx = tx0 + x;
-        if (gy < 0 || gy >= rows || gx < 0 || gx >= cols) return;
-        float v[25];
-#pragma unroll
-        for (int dy = 0; dy < 5; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 5; ++dx) v[dy * 5 + dx] = A[(y + dy - 2) * P + x + dx - 2];
-        B[y * P + x] = median25(v);
-    });
+    // H9 on tile +- 2: one thread per (column, segment of kSeg rows) streams down its rows with the time-shared
+    // networks of dcmt_median.h -- 16 row sorts and 8 pair merges for 12 medians instead of 12 full 25-input networks
+    // (~50 instead of ~230 min/max per pixel, 80 instead of 300 LDS reads).  A is replicate-padded, so every position of
+    // the region has its full window; positions outside the image are computed and never read.
+    {
+        constexpr int kSeg = 12, kCols = RW - 4, kSegs = (RH - 4 + kSeg - 1) / kSeg;
+        for (int t = threadIdx.x; t < kCols * kSegs; t += kThreads) {
+            const int x = 2 + t % kCols, y0 = 2 + (t / kCols) * kSeg;           // medians of rows y0 .. y0 + kSeg - 1
+            MedianColumn mc;
+            static_for<0, kSeg + 4>([&](auto U_) {
+                constexpr int u = decltype(U_)::value;
+                const int yi = min(y0 - 2 + u, RH - 1);                          // input row (clamped only in a short last segment)
+                const float* a = A + yi * P + x;
+                float s5[5] = {a[-2], a[-1], a[0], a[1], a[2]};
+                sort5(s5);
+                const float m = mc.template step<(u & 7)>(s5);
+                if constexpr (u >= 4) {
+                    const int yo = y0 + u - 4;
+                    if (yo < RH - 2) B[yo * P + x] = m;
+                }
+            });
+        }
+    }
     __syncthreads();
     const bool do_blur = blur == 1 && mode >= 10;
     if (do_blur) {
