@@ -566,10 +566,7 @@ __device__ __forceinline__ float gauss_taps(float c, float s1, float s2)
 template <int MODE, bool BLUR>
 struct PostPipe {
     static constexpr bool do_blur = BLUR && MODE >= 10;
-    float SE[4][5];          // sorted even rows u = 2q, slot q & 3
-    float SO[5];             // the latest sorted odd row
-    float P[2][10];          // merged pairs (rows 2q-1, 2q), slot q & 1
-    float C[6];              // middle order statistics of the current 4-row core
+    MedianColumn mc;         // the vertical half of the median (dcmt_median.h)
     float G1[8], MR[8];      // horizontal Gaussian / median rows, slot (image row) & 7
     // per-lane constants
     FrameBuf of;             // output frame
@@ -586,16 +583,7 @@ struct PostPipe {
         outlane = gx >= 0 && gx < cols && lane >= PostS::H && lane < 64 - PostS::H;
         rl = reflect101(gx, cols) - gx0;      // reflect-101 source lane for the Gaussian's out-of-image columns
         edge_strip = gx0 < 0 || gx0 + 63 >= cols;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < 5; ++k) SE[q][k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) SO[k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) { P[0][k] = 0.f; P[1][k] = 0.f; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) C[k] = 0.f;
+        mc.init();
 #pragma unroll
         for (int q = 0; q < 8; ++q) { G1[q] = 0.f; MR[q] = 0.f; }
     }
@@ -610,19 +598,7 @@ struct PostPipe {
             s[0] = from_left(l1); s[1] = l1; s[2] = x; s[3] = r1; s[4] = from_right(r1);
         }
         sort5(s);
-        float m;
-        if constexpr ((PP & 1) == 0) {                                // u = 2q
-            constexpr int qs = (PP >> 1) & 3;
-            merge55(SO, s, P[(PP >> 1) & 1]);                         // rows u-1, u
-            mid20(P[((PP >> 1) + 1) & 1], P[(PP >> 1) & 1], C);       // core rows u-3 .. u
-            m = final6(C, SE[(qs + 2) & 3]);                          // + row u-4
-#pragma unroll
-            for (int k = 0; k < 5; ++k) SE[qs][k] = s[k];
-        } else {                                                      // u = 2q + 1
-            m = final6(C, s);                                         // core rows u-4 .. u-1, + row u
-#pragma unroll
-            for (int k = 0; k < 5; ++k) SO[k] = s[k];
-        }
+        const float m = mc.template step<PP>(s);                       // median of the window whose bottom row is u
         const int j = u - 4;                                           // image row of this median
         if constexpr (MODE == 9) {
             if ((unsigned)j < (unsigned)rows && outlane) of.st(ob, j, cols, m);

@@ -710,6 +710,7 @@ void k_post_v1(const float* __restrict__ pp0, const float* __restrict__ pp1, flo
         for (int t = threadIdx.x; t < kCols * kSegs; t += kThreads) {
             const int x = 2 + t % kCols, y0 = 2 + (t / kCols) * kSeg;           // medians of rows y0 .. y0 + kSeg - 1
             MedianColumn mc;
+            mc.init();
             static_for<0, kSeg + 4>([&](auto U_) {
                 constexpr int u = decltype(U_)::value;
                 const int yi = min(y0 - 2 + u, RH - 1);                          // input row (clamped only in a short last segment)

@@ -92,6 +92,19 @@ struct MedianColumn {
     float SO[5];             // the latest sorted odd row
     float P[2][10];          // merged pairs (rows 2q-1, 2q), slot q & 1
     float C[6];              // middle order statistics of the current 4-row core
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SE[q][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) SO[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { P[0][k] = 0.f; P[1][k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = 0.f;
+    }
     template <int PP>
     __device__ __forceinline__ float step(const float (&s)[5])
     {
