@@ -27,7 +27,7 @@ struct dcmt_ctx {
     // device scratch
     float* x5 = nullptr;              // [max_batch][rows][cols] : cascade after the small fill
     float* pp[2] = {nullptr, nullptr};// ping-pong of the large-fill applications
-    int* colstat = nullptr;           // [max_batch][2][cols]
+    int* colstat = nullptr;           // [max_batch][tile rows][2][cols]  (staged path)
     int* counters = nullptr;          // [max_batch][kCntStride]
     uint32_t* norm_stats = nullptr;   // [max_batch][2]  N1: order-preserving keys of each frame's max and (inverted) min
     float* norm_coef = nullptr;       // [max_batch][2]  N1: dst = src * a + b
@@ -368,20 +368,14 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     ctx->last_apps_launched = 0;
     ctx->last_has_loop = 0;
 
-    {
-        const long n = (long)batch * (2L * cols + kCntStride);
-        int blocks = (int)((n + 255) / 256);
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, st, ctx->colstat, ctx->counters, cols, batch);
-    }
     const int dump = stop <= DCMT_STAGE_CLOSE5 ? stop : 0;
     if (d_labels && use_superpixel) {
         hipLaunchKernelGGL((k_pre_labeled_v1<TH, TW>), grid, block, 0, st, d_src, d_labels, n_labels,
-                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, d_dst, rows, cols,
+                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
                            p->max_depth, p->valid_thresh, kb, dump, coef);
     } else {
         hipLaunchKernelGGL((k_pre_v1<TH, TW>), grid, block, 0, st, d_src,
-                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, d_dst, rows, cols,
+                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
                            p->max_depth, p->valid_thresh, kb, dump, coef);
     }
     DCMT_HIP(ctx, hipGetLastError());
@@ -553,7 +547,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->x5, plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[0], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + TH - 1) / TH) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);

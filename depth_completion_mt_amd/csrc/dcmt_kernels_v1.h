@@ -243,20 +243,15 @@ void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
-// init: column statistics and counters for one call
+// Per-call state of the staged path, without an init launch (a dependent launch costs ~5 us, as much as a quarter of a
+// stage on a single frame): the column statistics are kept per TILE ROW -- colstat[frame][tile row][2][cols], every entry
+// written exactly once by the workgroup that owns that tile, no atomics across workgroups -- and reduced over the tile rows
+// by the reader (k_fill31_v1); the hole counters of a frame are zeroed by the first workgroup of the first kernel.
 // ---------------------------------------------------------------------------------
-__global__ void k_init(int* __restrict__ colstat, int* __restrict__ counters, int cols, int batch)
+__device__ __forceinline__ void zero_frame_counters(int* __restrict__ counters, int f)
 {
-    const long n_cs = (long)batch * 2 * cols;
-    const long n_ct = (long)batch * kCntStride;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_cs + n_ct; i += (long)gridDim.x * blockDim.x) {
-        if (i < n_cs) {
-            const long f2 = i / cols;                 // frame*2 + which
-            colstat[i] = (f2 & 1) ? -1 : 0x7fffffff;  // [f][0][c] = first valid row (min), [f][1][c] = last (max)
-        } else {
-            counters[i - n_cs] = 0;
-        }
-    }
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < kCntStride; i += kThreads) counters[(size_t)f * kCntStride + i] = 0;
 }
 
 // ---------------------------------------------------------------------------------
@@ -302,12 +297,9 @@ __device__ __forceinline__ void small_fill_and_stats(float* A, float* B, int* sm
         }
     });
     __syncthreads();
-    for (int i = threadIdx.x; i < TW; i += kThreads) {
+    for (int i = threadIdx.x; i < TW; i += kThreads) {              // this tile row's slot: first / last valid row, or none
         const int gx = tx0 + R + i;
-        if (gx < cols && smax[i] >= 0) {
-            atomicMin(&colstat_f[gx], smin[i]);
-            atomicMax(&colstat_f[cols + gx], smax[i]);
-        }
+        if (gx < cols) { colstat_f[gx] = smin[i]; colstat_f[cols + gx] = smax[i]; }
     }
 }
 
@@ -324,10 +316,11 @@ __device__ __forceinline__ void dump_plane(const float* plane, float* __restrict
 
 template <int TH, int TW>
 __global__ __launch_bounds__(kThreads)
-void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __restrict__ colstat,
+void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __restrict__ colstat, int* __restrict__ counters,
               float* __restrict__ dump, int rows, int cols, float max_depth, float thr,
               uint32_t k0bits, int dump_stage, const float* __restrict__ coef)
 {
+    zero_frame_counters(counters, blockIdx.z);
     using G = PreGeom<TH, TW>;
     constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
     __shared__ float A[RH * P];
@@ -396,7 +389,7 @@ void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __rest
     __syncthreads();
     if (dump_stage == 4) { dump_plane<TH, TW>(B, dump + fo, rows, cols, ty0, tx0); return; }
 
-    small_fill_and_stats<TH, TW>(A, B, smin, smax, x5 + fo, colstat + (size_t)f * 2 * cols, rows, cols, ty0, tx0, thr);
+    small_fill_and_stats<TH, TW>(A, B, smin, smax, x5 + fo, colstat + ((size_t)f * gridDim.y + blockIdx.y) * 2 * cols, rows, cols, ty0, tx0, thr);
 }
 
 // ---------------------------------------------------------------------------------
@@ -411,10 +404,11 @@ void k_pre_v1(const float* __restrict__ src, float* __restrict__ x5, int* __rest
 template <int TH, int TW>
 __global__ __launch_bounds__(kThreads)
 void k_pre_labeled_v1(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
-                      float* __restrict__ x5, int* __restrict__ colstat, float* __restrict__ dump,
+                      float* __restrict__ x5, int* __restrict__ colstat, int* __restrict__ counters, float* __restrict__ dump,
                       int rows, int cols, float max_depth, float thr, uint32_t k0bits, int dump_stage,
                       const float* __restrict__ coef)
 {
+    zero_frame_counters(counters, blockIdx.z);
     using G = PreGeom<TH, TW>;
     constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
     __shared__ float X0[RH * P];     // H2 output (never modified)
@@ -522,7 +516,7 @@ void k_pre_labeled_v1(const float* __restrict__ src, const int32_t* __restrict__
     // X4 outside the image must be the border value of the 7x7 dilate; it is (-FLT_MAX from the load)
     if (dump_stage == 3 || dump_stage == 4) { dump_plane<TH, TW>(X4, dump + fo, rows, cols, ty0, tx0); return; }
 
-    small_fill_and_stats<TH, TW>(A, X4, smin, smax, x5 + fo, colstat + (size_t)f * 2 * cols, rows, cols, ty0, tx0, thr);
+    small_fill_and_stats<TH, TW>(A, X4, smin, smax, x5 + fo, colstat + ((size_t)f * gridDim.y + blockIdx.y) * 2 * cols, rows, cols, ty0, tx0, thr);
 }
 
 // ---------------------------------------------------------------------------------
@@ -563,12 +557,16 @@ void k_fill31_v1(const float* __restrict__ in, float* __restrict__ out, const in
 
     if (threadIdx.x == 0) { s_before = 0; s_after = 0; }
     if (app == 0) {
-        const int* cs = colstat + (size_t)f * 2 * cols;
+        const int* cs = colstat + (size_t)f * gridDim.y * 2 * cols;      // [tile row][2][cols]
         for (int x = threadIdx.x; x < RW; x += kThreads) {
             const int gx = tx0 + x;
             int ti = 0, bi = -1; float tv = 0.f, bv = 0.f;
             if (gx >= 0 && gx < cols) {
-                ti = cs[gx]; bi = cs[cols + gx];
+                ti = 0x7fffffff;
+                for (int tr = 0; tr < (int)gridDim.y; ++tr) {
+                    ti = min(ti, cs[(size_t)tr * 2 * cols + gx]);
+                    bi = max(bi, cs[(size_t)tr * 2 * cols + cols + gx]);
+                }
                 if (bi >= 0) { tv = xin[(size_t)ti * cols + gx]; bv = xin[(size_t)bi * cols + gx]; }
             }
             cti[x] = ti; cbi[x] = bi; ctv[x] = tv; cbv[x] = bv;
