@@ -64,6 +64,8 @@ struct dcmt_ctx {
 namespace {
 
 constexpr int TH = 32, TW = 64;
+constexpr int FTH_FEW = 16;          // tile height of the staged 31x31 fill for one or two frames: twice the workgroups, shorter
+                                     // critical path (a single frame's 209 tiles of 32 rows leave a fifth of the CUs idle)
 
 #define DCMT_HIP(ctx, call)                                        \
     do {                                                           \
@@ -281,6 +283,10 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
               hipStream_t st, bool sync_loop, const uint16_t* d_src16 = nullptr, float in_scale = 1.0f)
 {
     const dim3 grid = tile_grid(rows, cols, batch), block(kThreads);
+    const bool few = batch <= 2;
+    const dim3 fgrid((cols + TW - 1) / TW, few ? (rows + FTH_FEW - 1) / FTH_FEW : (rows + TH - 1) / TH, batch);
+#define DCMT_FILL31(...) { if (few) hipLaunchKernelGGL((k_fill31_v1<FTH_FEW, TW>), fgrid, block, 0, st, __VA_ARGS__); \
+                           else hipLaunchKernelGGL((k_fill31_v1<TH, TW>), fgrid, block, 0, st, __VA_ARGS__); }
     const uint32_t kb = k0_bits(p->k0);
     const int stop = p->stop_after;
     const int blur = force_gaussian ? (int)DCMT_BLUR_GAUSSIAN : p->blur;
@@ -383,14 +389,11 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
 
     // H6 + H7
     if (stop == DCMT_STAGE_EXTEND) {
-        hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->x5, d_dst, ctx->colstat, ctx->counters,
-                           rows, cols, p->valid_thresh, 0, 1);
+        DCMT_FILL31(ctx->x5, d_dst, ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, 0, 1, (int)grid.y)
         DCMT_HIP(ctx, hipGetLastError());
         return DCMT_OK;
     }
-    hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->x5,
-                       stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0], ctx->colstat, ctx->counters,
-                       rows, cols, p->valid_thresh, 0, 0);
+    DCMT_FILL31(ctx->x5, stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0], ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, 0, 0, (int)grid.y)
     DCMT_HIP(ctx, hipGetLastError());
     if (stop == DCMT_STAGE_FILL31) return DCMT_OK;
 
@@ -398,8 +401,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     ctx->last_has_loop = 1;
     int apps = 0;
     const int rc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
-        hipLaunchKernelGGL((k_fill31_v1<TH, TW>), grid, block, 0, st, ctx->pp[(i - 1) & 1], ctx->pp[i & 1], ctx->colstat,
-                           ctx->counters, rows, cols, p->valid_thresh, i, 0);
+        DCMT_FILL31(ctx->pp[(i - 1) & 1], ctx->pp[i & 1], ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, i, 0, (int)grid.y)
     }, &apps);
     if (rc != DCMT_OK && rc != DCMT_E_NOT_CONVERGED) return rc;
     ctx->last_apps_launched = apps;
@@ -409,6 +411,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
                        rows, cols, p->max_depth, p->valid_thresh, blur, mode);
     DCMT_HIP(ctx, hipGetLastError());
     return rc;
+#undef DCMT_FILL31
 }
 
 int ensure_host_staging(dcmt_ctx* ctx, bool labels)

@@ -536,8 +536,9 @@ struct FillGeom {
 template <int TH, int TW>
 __global__ __launch_bounds__(kThreads)
 void k_fill31_v1(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ colstat,
-                 int* __restrict__ counters, int rows, int cols, float thr, int app, int dump_extend)
+                 int* __restrict__ counters, int rows, int cols, float thr, int app, int dump_extend, int stat_rows)
 {
+    // stat_rows: tile rows of the kernel that wrote colstat (its tiles may be taller than this kernel's)
     using G = FillGeom<TH, TW>;
     constexpr int R = G::R, RH = G::RH, RW = G::RW, P = G::P;
     __shared__ float A[RH * P];
@@ -557,13 +558,13 @@ void k_fill31_v1(const float* __restrict__ in, float* __restrict__ out, const in
 
     if (threadIdx.x == 0) { s_before = 0; s_after = 0; }
     if (app == 0) {
-        const int* cs = colstat + (size_t)f * gridDim.y * 2 * cols;      // [tile row][2][cols]
+        const int* cs = colstat + (size_t)f * stat_rows * 2 * cols;      // [tile row][2][cols]
         for (int x = threadIdx.x; x < RW; x += kThreads) {
             const int gx = tx0 + x;
             int ti = 0, bi = -1; float tv = 0.f, bv = 0.f;
             if (gx >= 0 && gx < cols) {
                 ti = 0x7fffffff;
-                for (int tr = 0; tr < (int)gridDim.y; ++tr) {
+                for (int tr = 0; tr < stat_rows; ++tr) {
                     ti = min(ti, cs[(size_t)tr * 2 * cols + gx]);
                     bi = max(bi, cs[(size_t)tr * 2 * cols + cols + gx]);
                 }
