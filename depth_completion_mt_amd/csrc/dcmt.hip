@@ -375,10 +375,16 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     ctx->last_has_loop = 0;
 
     const int dump = stop <= DCMT_STAGE_CLOSE5 ? stop : 0;
+    int stat_rows = (int)grid.y;                   // tile rows of the kernel that writes the column statistics
     if (d_labels && use_superpixel) {
         hipLaunchKernelGGL((k_pre_labeled_v1<TH, TW>), grid, block, 0, st, d_src, d_labels, n_labels,
                            stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
                            p->max_depth, p->valid_thresh, kb, dump, coef);
+    } else if (few) {
+        hipLaunchKernelGGL((k_pre_v1<FTH_FEW, TW>), fgrid, block, 0, st, d_src,
+                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
+                           p->max_depth, p->valid_thresh, kb, dump, coef);
+        stat_rows = (int)fgrid.y;
     } else {
         hipLaunchKernelGGL((k_pre_v1<TH, TW>), grid, block, 0, st, d_src,
                            stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
@@ -389,11 +395,11 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
 
     // H6 + H7
     if (stop == DCMT_STAGE_EXTEND) {
-        DCMT_FILL31(ctx->x5, d_dst, ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, 0, 1, (int)grid.y)
+        DCMT_FILL31(ctx->x5, d_dst, ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, 0, 1, stat_rows)
         DCMT_HIP(ctx, hipGetLastError());
         return DCMT_OK;
     }
-    DCMT_FILL31(ctx->x5, stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0], ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, 0, 0, (int)grid.y)
+    DCMT_FILL31(ctx->x5, stop == DCMT_STAGE_FILL31 ? d_dst : ctx->pp[0], ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, 0, 0, stat_rows)
     DCMT_HIP(ctx, hipGetLastError());
     if (stop == DCMT_STAGE_FILL31) return DCMT_OK;
 
@@ -401,7 +407,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     ctx->last_has_loop = 1;
     int apps = 0;
     const int rc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
-        DCMT_FILL31(ctx->pp[(i - 1) & 1], ctx->pp[i & 1], ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, i, 0, (int)grid.y)
+        DCMT_FILL31(ctx->pp[(i - 1) & 1], ctx->pp[i & 1], ctx->colstat, ctx->counters, rows, cols, p->valid_thresh, i, 0, stat_rows)
     }, &apps);
     if (rc != DCMT_OK && rc != DCMT_E_NOT_CONVERGED) return rc;
     ctx->last_apps_launched = apps;
@@ -550,7 +556,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->x5, plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[0], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + TH - 1) / TH) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + FTH_FEW - 1) / FTH_FEW) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
