@@ -413,8 +413,10 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     ctx->last_apps_launched = apps;
 
     const int mode = stop <= DCMT_STAGE_FILLLOOP ? 8 : stop;
-    hipLaunchKernelGGL((k_post_v1<TH, TW>), grid, block, 0, st, ctx->pp[0], ctx->pp[1], d_dst, ctx->counters, apps,
-                       rows, cols, p->max_depth, p->valid_thresh, blur, mode);
+    if (few) hipLaunchKernelGGL((k_post_v1<FTH_FEW, TW>), fgrid, block, 0, st, ctx->pp[0], ctx->pp[1], d_dst, ctx->counters, apps,
+                                rows, cols, p->max_depth, p->valid_thresh, blur, mode);
+    else hipLaunchKernelGGL((k_post_v1<TH, TW>), grid, block, 0, st, ctx->pp[0], ctx->pp[1], d_dst, ctx->counters, apps,
+                            rows, cols, p->max_depth, p->valid_thresh, blur, mode);
     DCMT_HIP(ctx, hipGetLastError());
     return rc;
 #undef DCMT_FILL31
