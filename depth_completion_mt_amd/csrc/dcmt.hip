@@ -64,7 +64,7 @@ struct dcmt_ctx {
 namespace {
 
 constexpr int TH = 32, TW = 64;
-constexpr int FTH_FEW = 16;          // tile height of the staged 31x31 fill for one or two frames: twice the workgroups, shorter
+constexpr int FTH_FEW = 16;          // tile height of the staged kernels for a handful of frames: twice the workgroups, a shorter
                                      // critical path (a single frame's 209 tiles of 32 rows leave a fifth of the CUs idle)
 
 #define DCMT_HIP(ctx, call)                                        \
@@ -283,7 +283,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
               hipStream_t st, bool sync_loop, const uint16_t* d_src16 = nullptr, float in_scale = 1.0f)
 {
     const dim3 grid = tile_grid(rows, cols, batch), block(kThreads);
-    const bool few = batch <= 2;
+    const bool few = batch < 12;                    // measured up to 8 frames (tools/batch_sweep.py): +15 % at 3 and 6, +7 % at 8
     const dim3 fgrid((cols + TW - 1) / TW, few ? (rows + FTH_FEW - 1) / FTH_FEW : (rows + TH - 1) / TH, batch);
 #define DCMT_FILL31(...) { if (few) hipLaunchKernelGGL((k_fill31_v1<FTH_FEW, TW>), fgrid, block, 0, st, __VA_ARGS__); \
                            else hipLaunchKernelGGL((k_fill31_v1<TH, TW>), fgrid, block, 0, st, __VA_ARGS__); }

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from depth_completion_mt_amd import Context, make_params, synth
 src = torch.from_numpy(synth.synth_batch(64, 352, 1216, 0)).cuda()
-for B in (1, 2, 4, 8, 16, 32, 64):
+for B in (tuple(int(a) for a in sys.argv[1:]) or (1, 2, 4, 8, 16, 32, 64)):
     ctx = Context(0, 352, 1216, B)
     d = src[:B].contiguous(); o = torch.empty_like(d)
     row = []
