@@ -376,7 +376,12 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
 
     const int dump = stop <= DCMT_STAGE_CLOSE5 ? stop : 0;
     int stat_rows = (int)grid.y;                   // tile rows of the kernel that writes the column statistics
-    if (d_labels && use_superpixel) {
+    if (d_labels && use_superpixel && few) {
+        hipLaunchKernelGGL((k_pre_labeled_v1<FTH_FEW, TW>), fgrid, block, 0, st, d_src, d_labels, n_labels,
+                           stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
+                           p->max_depth, p->valid_thresh, kb, dump, coef);
+        stat_rows = (int)fgrid.y;
+    } else if (d_labels && use_superpixel) {
         hipLaunchKernelGGL((k_pre_labeled_v1<TH, TW>), grid, block, 0, st, d_src, d_labels, n_labels,
                            stop == DCMT_STAGE_FILL7 ? d_dst : ctx->x5, ctx->colstat, ctx->counters, d_dst, rows, cols,
                            p->max_depth, p->valid_thresh, kb, dump, coef);
