@@ -213,8 +213,10 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             // one kernel for H7..H11; frames it leaves with holes are redone by the unfused kernels below
             const int pstrips = (cols + PostS::VW - 1) / PostS::VW;
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
-            if (bl) hipLaunchKernelGGL((k_fp_s<true>), pg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
-            else    hipLaunchKernelGGL((k_fp_s<false>), pg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
+            // k_fp_s deals (frame, strip) pairs to waves in one flat sequence (per XCD with the XCD map): no half-empty workgroups
+            const dim3 fpg(xm ? 8 * (((nb / 8) * pstrips + 3) / 4) : (nb * pstrips + 3) / 4);
+            if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
+            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
             DCMT_HIP(ctx, hipGetLastError());
             ctx->last_has_loop = 1;
             const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);

@@ -845,11 +845,21 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     // maxima (only its 30 halo lanes: packed to 32) -- 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
     __shared__ float s_delay[4][16 * (64 + 64 + 32)];
     const int lane = threadIdx.x & 63;
-    int f, sg;
-    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int strip = sg * 4 + wave;
-    if (strip >= strips) return;
+    // (frame, strip) pairs are dealt to waves in one flat sequence, so a strip count that is not a multiple of 4 (22 at 1216
+    // columns) leaves no workgroup with idle waves holding its LDS; with xcd_map the sequence runs per XCD over its frames
+    int f, strip;
+    if (xcd_map) {
+        const int g = (blockIdx.x >> 3) * 4 + wave;
+        if (g >= (batch >> 3) * strips) return;
+        f = (g / strips) * 8 + (blockIdx.x & 7);
+        strip = g % strips;
+    } else {
+        const int g = blockIdx.x * 4 + wave;
+        if (g >= batch * strips) return;
+        f = g / strips;
+        strip = g % strips;
+    }
     int* cnt = frame_counters(counters, f);
     const size_t fo = (size_t)f * rows * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
