@@ -107,6 +107,12 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
     return DCMT_OK;
 }
 
+// grid of the kernels that deal (frame, strip) pairs to waves in one flat sequence (wave_strip in dcmt_kernels_fused.h)
+dim3 wave_grid(int strips, int batch, int xcd_map)
+{
+    return dim3(xcd_map ? 8 * (((batch / 8) * strips + 3) / 4) : (batch * strips + 3) / 4);
+}
+
 dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
 
 int k0_preset(uint32_t kb)
@@ -193,13 +199,13 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const bool wide = ctx->wide && cols % 4 == 0 && ((uintptr_t)src % 16 == 0) && !d_src16;
             const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr;
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
-                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
+                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
                                              rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr); \
-                else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src16, o6, \
+                else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src16, o6, \
                                              rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr); \
-                else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
+                else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
                                         rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf); \
-                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), dim3(((strips + 3) / 4) * nb), dim3(256), 0, st, (const void*)src, o6, \
+                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
                                         rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr); }
             if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
             else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
@@ -214,7 +220,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const int pstrips = (cols + PostS::VW - 1) / PostS::VW;
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
             // k_fp_s deals (frame, strip) pairs to waves in one flat sequence (per XCD with the XCD map): no half-empty workgroups
-            const dim3 fpg(xm ? 8 * (((nb / 8) * pstrips + 3) / 4) : (nb * pstrips + 3) / 4);
+            const dim3 fpg = wave_grid(pstrips, nb, xm);
             if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
             else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
             DCMT_HIP(ctx, hipGetLastError());

@@ -106,6 +106,26 @@ __device__ __forceinline__ void frame_unit(int b, int units, int batch, int xcd_
     (void)batch;
 }
 
+// Wave -> (frame, strip) for the kernels that give every wave one strip: the pairs are dealt to waves in one flat
+// sequence, so a strip count that is not a multiple of 4 (22 post strips at 1216 columns) leaves no workgroup with idle
+// waves holding its LDS; with xcd_map the sequence runs per XCD over that XCD's frames.  Returns false for the waves past
+// the end.  Grid: wave_grid().
+__device__ __forceinline__ bool wave_strip(int b, int wave, int strips, int batch, int xcd_map, int& f, int& strip)
+{
+    if (xcd_map) {
+        const int g = (b >> 3) * 4 + wave;
+        if (g >= (batch >> 3) * strips) return false;
+        f = (g / strips) * 8 + (b & 7);
+        strip = g % strips;
+    } else {
+        const int g = b * 4 + wave;
+        if (g >= batch * strips) return false;
+        f = g / strips;
+        strip = g % strips;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------
 // RowRing: wave-private LDS ring filled by LDS-DMA.  One global_load_lds_dwordx4 moves a 4-row
 // x 64-column block (64 lanes x 16 B, the widest access) for the wave's strip straight into
@@ -189,10 +209,9 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
     __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * 4 * 256 : 4];   // 4 waves x 4 slots x (4 rows x 64 columns)
     const int lane = threadIdx.x & 63;
-    int f, sg;
-    frame_unit(blockIdx.x, (strips + 3) / 4, batch, xcd_map, f, sg);
-    const int strip = sg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
-    if (strip >= strips) return;                 // whole waves leave; no barrier is used below
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);             // wave-uniform: keep it scalar
+    int f, strip;
+    if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;   // whole waves leave; no barrier is used below
     const int gx = strip * G::VW - G::HL + lane;
     const bool incol = gx >= 0 && gx < cols;
     const bool outlane = incol && lane >= G::HL && lane < G::HL + G::VW;
@@ -210,7 +229,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
         else return ib.ld(oc, r, cols);
     };
     RowRing<4, ROFF> rr;
-    if constexpr (WIDE) rr.init(s_ring + (strip & 3) * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
+    if constexpr (WIDE) rr.init(s_ring + wave * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
 
     constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
     // rolling rows, indexed by (row & 7); fully unrolled below so every index is static
@@ -846,20 +865,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     __shared__ float s_delay[4][16 * (64 + 64 + 32)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // (frame, strip) pairs are dealt to waves in one flat sequence, so a strip count that is not a multiple of 4 (22 at 1216
-    // columns) leaves no workgroup with idle waves holding its LDS; with xcd_map the sequence runs per XCD over its frames
     int f, strip;
-    if (xcd_map) {
-        const int g = (blockIdx.x >> 3) * 4 + wave;
-        if (g >= (batch >> 3) * strips) return;
-        f = (g / strips) * 8 + (blockIdx.x & 7);
-        strip = g % strips;
-    } else {
-        const int g = blockIdx.x * 4 + wave;
-        if (g >= batch * strips) return;
-        f = g / strips;
-        strip = g % strips;
-    }
+    if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;
     int* cnt = frame_counters(counters, f);
     const size_t fo = (size_t)f * rows * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
