@@ -247,6 +247,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     constexpr int PFD = DCMT_PRE_PFD;            // rows of load lookahead (dword path)
     if constexpr (WIDE) {
         rr.issue(0); rr.issue(1); rr.issue(2);   // three 4-row blocks ahead
+        rr.template wait<0>();                   // from here on the counted waits below see a fixed pattern of younger operations
     } else {
 #pragma unroll
         for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(q - ROFF, 0), rows - 1));
@@ -262,7 +263,10 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // ---- H2 on load (LO :55-67); outside the image: the dilate border value
             float raw;
             if constexpr (WIDE) {
-                if ((p & 3) == 0) { rr.issue((i >> 2) + 3); rr.template wait<3>(); }
+                // gfx9 counts loads and stores in ONE counter, in issue order.  Every step issues exactly one store (below), so
+                // behind the block needed now there are always 3 younger DMAs and 12 stores: vmcnt(15) waits for exactly that block
+                // and leaves the prefetch and the stores in flight (vmcnt(3) would also wait for all but two of the stores).
+                if ((p & 3) == 0) { rr.issue((i >> 2) + 3); rr.template wait<15>(); }
                 raw = rr.read(i, lane);
             } else {
                 raw = PF[p];
@@ -315,15 +319,19 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             const float d7 = fmax3(T7[p], T7[(p + 5) & 7] /* rows i-11 .. i-9 */, H7[(p + 4) & 7] /* row i-12 */);
             const float e = E4[(p + 7) & 7];                             // row m = i-9
             const float x5 = e < thr ? d7 : e;
-            if ((unsigned)m < (unsigned)rows) {
+            const bool inrows = (unsigned)m < (unsigned)rows;
+            if (inrows) {
                 // ---- H6 bookkeeping (LO :112-121): first / last row with x > 0.1 (their values are re-read
                 // from the rows stored below, in the epilogue)
                 const bool valid = x5 >= thr;
                 ti = min(ti, valid ? m : 0x7fffffff);
                 bi = valid ? m : bi;
-                // rows above the first valid one are written by the epilogue
-                if (outlane && m >= ti) ob.st(oc, m, cols, x5);
             }
+            // rows above the first valid one are written by the epilogue.  The store instruction itself is issued on every step
+            // by every lane (the DMA waits above count on it): lanes and steps with nothing to write aim past the end of the
+            // buffer resource, where the hardware drops the write
+            if constexpr (WIDE) ob.st((inrows && outlane && m >= ti) ? oc : 0x7ffffff0u, inrows ? m : 0, cols, x5);
+            else if (inrows && outlane && m >= ti) ob.st(oc, m, cols, x5);
         }
     }
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
