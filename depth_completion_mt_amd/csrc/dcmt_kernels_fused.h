@@ -207,7 +207,11 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     const float* src = static_cast<const float*>(src_);
     using G = PreS<K0KIND, WIDE>;
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
-    __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * 4 * 256 : 4];   // 4 waves x 4 slots x (4 rows x 64 columns)
+#ifndef DCMT_PRE_SLOTS
+#define DCMT_PRE_SLOTS 8
+#endif
+    constexpr int SLOTS = DCMT_PRE_SLOTS, AHEAD = SLOTS - 1;      // ring slots per wave; 4-row blocks in flight
+    __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * SLOTS * 256 : 4];   // 4 waves x SLOTS x (4 rows x 64 columns)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);             // wave-uniform: keep it scalar
     int f, strip;
@@ -228,8 +232,8 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
         if constexpr (U16) return __fmul_rn((float)sp16[(size_t)r * cols], in_scale);
         else return ib.ld(oc, r, cols);
     };
-    RowRing<4, ROFF> rr;
-    if constexpr (WIDE) rr.init(s_ring + wave * 4 * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
+    RowRing<SLOTS, ROFF> rr;
+    if constexpr (WIDE) rr.init(s_ring + wave * SLOTS * 256, src + fo, rows, cols, strip * G::VW - G::HL, lane);
 
     constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
     // rolling rows, indexed by (row & 7); fully unrolled below so every index is static
@@ -246,7 +250,8 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 #endif
     constexpr int PFD = DCMT_PRE_PFD;            // rows of load lookahead (dword path)
     if constexpr (WIDE) {
-        rr.issue(0); rr.issue(1); rr.issue(2);   // three 4-row blocks ahead
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) rr.issue(q);   // AHEAD 4-row blocks ahead
         rr.template wait<0>();                   // from here on the counted waits below see a fixed pattern of younger operations
     } else {
 #pragma unroll
@@ -264,9 +269,9 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             float raw;
             if constexpr (WIDE) {
                 // gfx9 counts loads and stores in ONE counter, in issue order.  Every step issues exactly one store (below), so
-                // behind the block needed now there are always 3 younger DMAs and 12 stores: vmcnt(15) waits for exactly that block
+                // behind the block needed now there are always AHEAD younger DMAs and 4 * AHEAD stores: that count waits for exactly that block
                 // and leaves the prefetch and the stores in flight (vmcnt(3) would also wait for all but two of the stores).
-                if ((p & 3) == 0) { rr.issue((i >> 2) + 3); rr.template wait<15>(); }
+                if ((p & 3) == 0) { rr.issue((i >> 2) + AHEAD); rr.template wait<5 * AHEAD>(); }
                 raw = rr.read(i, lane);
             } else {
                 raw = PF[p];
