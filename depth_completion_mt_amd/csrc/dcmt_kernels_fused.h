@@ -658,7 +658,7 @@ struct PostPipe {
                     if (mo >= thr) val = acc;                           // LO :184
                 }
                 if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
-                if (outlane) of.st(ob, o, cols, val);
+                of.st(outlane ? ob : 0x7ffffff0u, o, cols, val);     // every lane stores; halo lanes aim past the buffer (dropped)
             };
             const float g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7];
             const float g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];
