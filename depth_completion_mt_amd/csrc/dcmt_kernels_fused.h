@@ -914,7 +914,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
 #pragma unroll
     for (int q = 0; q < 16; ++q) { dl_c[q][lane] = NEG; dl_a[q][lane] = NEG; dl_b[q][lb] = NEG; }
 #ifndef DCMT_FP_PFD
-#define DCMT_FP_PFD 4
+#define DCMT_FP_PFD 6
 #endif
     constexpr int PFD = DCMT_FP_PFD;         // rows of load lookahead
 #pragma unroll
