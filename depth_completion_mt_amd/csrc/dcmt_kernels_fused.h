@@ -499,7 +499,8 @@ __device__ __forceinline__ void label_pipeline(const FrameBuf& sb, const FrameBu
             const IntT l = i - 6;
             const float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
             // write-back only where the label is this one (LC :101)
-            if (l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) ob.st_at(gb + 4u * (unsigned)(l * cols), e4);
+            // every lane stores on every step (exact load waits); the ones with nothing to write aim past the buffer (dropped)
+            ob.st_at((l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) ? gb + 4u * (unsigned)(l * cols) : 0x7ffffff0u, e4);
         }
     }
 }
