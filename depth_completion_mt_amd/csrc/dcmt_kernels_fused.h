@@ -335,8 +335,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // rows above the first valid one are written by the epilogue.  The store instruction itself is issued on every step
             // by every lane (the DMA waits above count on it): lanes and steps with nothing to write aim past the end of the
             // buffer resource, where the hardware drops the write
-            if constexpr (WIDE) ob.st((inrows && outlane && m >= ti) ? oc : 0x7ffffff0u, inrows ? m : 0, cols, x5);
-            else if (inrows && outlane && m >= ti) ob.st(oc, m, cols, x5);
+            ob.st((inrows && outlane && m >= ti) ? oc : 0x7ffffff0u, inrows ? m : 0, cols, x5);
         }
     }
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
