@@ -60,7 +60,7 @@ def build(force: bool = False) -> str:
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
     root = os.path.dirname(os.path.dirname(_CSRC))
-    srcs += [os.path.join(root, "include", "dcmt.h"), os.path.join(root, "tools", "median_shared_nets.h"), os.path.join(root, "tools", "median_shared_nets3.h")]
+    srcs += [os.path.join(root, "include", "dcmt.h")]
     stale = force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if stale:
         r = subprocess.run(["make", "-C", _CSRC, "-B", "libdcmt_hip.so"], capture_output=True, text=True)

@@ -213,7 +213,7 @@ static void cx_rows(float *lo, float *hi, int n)
     }
 }
 
-#include "../tools/median_shared_nets.h"
+#include "median_nets.h"
 
 void dcmt_oracle_median5(const float *src, float *dst, int rows, int cols)
 {
@@ -313,6 +313,12 @@ void dcmt_oracle_gaussian5(const float *src, float *dst, int rows, int cols)
     free(tmp);
 }
 
+/* Which median the chain runs: 0 = the row-vectorised networks (default; the CPU baseline), 1 = the definition
+ * (dcmt_oracle_median5_simple: gather 25, select the 13th), which shares nothing with the HIP kernels' networks.
+ * Process-wide; set it before calling the chain (tests only). */
+static int g_median_definitional = 0;
+void dcmt_oracle_use_definitional_median(int on) { g_median_definitional = on != 0; }
+
 /* ---- tail shared by both entry points: H5 .. H11 ---------------------------------- */
 static int chain_tail(float *x, float *scratch, int rows, int cols, const dcmt_oracle_params *p,
                       int blur, int *fill_iters, int *holes_after_extend)
@@ -344,7 +350,8 @@ static int chain_tail(float *x, float *scratch, int rows, int cols, const dcmt_o
     if (fill_iters) *fill_iters = iters;
     if (p->stop_after <= DCMT_O_STAGE_FILLLOOP) return rc;
     /* H9 median 5x5 (LO :170) */
-    dcmt_oracle_median5(x, scratch, rows, cols);
+    if (g_median_definitional) dcmt_oracle_median5_simple(x, scratch, rows, cols);
+    else dcmt_oracle_median5(x, scratch, rows, cols);
     memcpy(x, scratch, sizeof(float) * n);
     if (p->stop_after <= DCMT_O_STAGE_MEDIAN5) return rc;
     /* H10 Gaussian + masked select (LO :176-189); "bilateral" throws in OpenCV

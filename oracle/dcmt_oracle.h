@@ -89,6 +89,8 @@ void dcmt_oracle_dilate_rect_bruteforce(const float *src, float *dst, int rows, 
 void dcmt_oracle_erode_rect_bruteforce(const float *src, float *dst, int rows, int cols, int ksize);
 void dcmt_oracle_median5(const float *src, float *dst, int rows, int cols);          /* row-vectorised networks */
 void dcmt_oracle_median5_simple(const float *src, float *dst, int rows, int cols);   /* the definition */
+/* the chain entry points use the definition instead of the networks (process-wide switch; tests) */
+void dcmt_oracle_use_definitional_median(int on);
 void dcmt_oracle_gaussian5(const float *src, float *dst, int rows, int cols);
 void dcmt_oracle_extend_columns(float *x, int rows, int cols);
 

@@ -32,10 +32,12 @@ class Params(ctypes.Structure):
 def build(native: bool = False) -> str:
     """Compile the oracle with gcc if the .so is missing or stale; returns its path."""
     target = "libdcmt_oracle_native.so" if native else "libdcmt_oracle.so"
+    # DCMT_ORACLE_TARGET=libdcmt_oracle_asan.so: the sanitizer build (tests/test_oracle.py runs the golden set through it in a
+    # child process that preloads the sanitizer runtimes)
+    target = os.environ.get("DCMT_ORACLE_TARGET", target)
     so = os.path.join(_HERE, target)
-    src = os.path.join(_HERE, "dcmt_oracle.c")
-    hdr = os.path.join(_HERE, "dcmt_oracle.h")
-    stale = (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    deps = [os.path.join(_HERE, f) for f in ("dcmt_oracle.c", "dcmt_oracle.h", "median_nets.h")]
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps)
     if stale:
         subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
     return so
@@ -76,6 +78,8 @@ def lib(native: bool = False) -> ctypes.CDLL:
         for n in ("dcmt_oracle_median5", "dcmt_oracle_median5_simple", "dcmt_oracle_gaussian5"):
             getattr(L, n).argtypes = [fp, fp, ctypes.c_int, ctypes.c_int]
             getattr(L, n).restype = None
+        L.dcmt_oracle_use_definitional_median.argtypes = [ctypes.c_int]
+        L.dcmt_oracle_use_definitional_median.restype = None
         L.dcmt_oracle_extend_columns.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         L.dcmt_oracle_extend_columns.restype = None
         L.dcmt_oracle_normalize_minmax.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
@@ -92,6 +96,22 @@ def lib(native: bool = False) -> ctypes.CDLL:
         L.dcmt_oracle_synth_frame.restype = None
         _libs[native] = L
     return _libs[native]
+
+
+class definitional_median:
+    """Context manager: the chain entry points run dcmt_oracle_median5_simple (gather 25, select the 13th) instead of the
+    comparator networks -- an oracle that shares no network with the HIP kernels."""
+
+    def __init__(self, native: bool = False):
+        self._native = native
+
+    def __enter__(self):
+        lib(self._native).dcmt_oracle_use_definitional_median(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib(self._native).dcmt_oracle_use_definitional_median(0)
+        return False
 
 
 def _fp(a: np.ndarray):

@@ -320,16 +320,51 @@ def test_primitives_match_scipy_ndimage():
 
 
 def test_generated_median_networks_are_reproducible_and_proven(tmp_path):
-    """tools/median_shared_nets3.h is exactly what tools/gen_median_3in.py generates (the generator re-proves every rewrite
+    """csrc/median_shared_nets3.h is exactly what tools/gen_median_3in.py generates (the generator re-proves every rewrite
     with the 0/1 principle on sorted inputs and cross-checks random floats while it runs), and the closing five-med3
     chain selects the 6th smallest of sorted 6 + sorted 5."""
     import importlib.util, os, shutil
     from conftest import ROOT
-    src = os.path.join(ROOT, "tools")
-    for f in ("gen_median_3in.py", "median_shared_nets.h"):
-        shutil.copy(os.path.join(src, f), tmp_path / f)
+    src = os.path.join(ROOT, "depth_completion_mt_amd", "csrc")
+    shutil.copy(os.path.join(ROOT, "tools", "gen_median_3in.py"), tmp_path / "gen_median_3in.py")
+    shutil.copy(os.path.join(src, "median_shared_nets.h"), tmp_path / "median_shared_nets.h")
     spec = importlib.util.spec_from_file_location("gen3", str(tmp_path / "gen_median_3in.py"))
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     g.main()                                          # asserts inside: 0/1 proof + 20000 random merges per network + the final chain
     assert open(tmp_path / "median_shared_nets3.h").read() == open(os.path.join(src, "median_shared_nets3.h")).read()
+
+
+def test_chain_with_definitional_median_matches_networks(golden_meta):
+    """The chain oracle with dcmt_oracle_median5_simple (gather 25, select the 13th -- shares no comparator network with the HIP
+    kernels) reproduces the committed full-size checksums, i.e. equals the network median bit for bit at both frame sizes."""
+    for key, m in golden_meta["full"].items():
+        if key.startswith("lc_"):
+            continue
+        dims, seed = key.split("_seed")
+        rows, cols = (int(v) for v in dims.split("x"))
+        x = synth.synth_frame(rows, cols, int(seed))
+        with O.definitional_median():
+            y = O.img_completion(x)
+        assert sha(y) == m["out_sha256"], key
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """the CPU oracle runs its whole test file under -fsanitize=address,undefined (oracle/Makefile,
+    libdcmt_oracle_asan.so) in a child process that preloads the sanitizer runtimes; any report aborts the child."""
+    import os, shutil, subprocess, sys
+    from conftest import ROOT
+    if os.environ.get("DCMT_ORACLE_TARGET"):
+        pytest.skip("already inside the sanitizer run")
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    libs = [subprocess.run([gcc, f"-print-file-name={n}"], capture_output=True, text=True, check=True).stdout.strip()
+            for n in ("libasan.so", "libubsan.so")]
+    assert all(os.path.isabs(p) and os.path.exists(p) for p in libs), libs
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libdcmt_oracle_asan.so"], check=True, capture_output=True)
+    env = dict(os.environ, DCMT_ORACLE_TARGET="libdcmt_oracle_asan.so", LD_PRELOAD=" ".join(libs),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not definitional"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]

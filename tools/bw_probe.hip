@@ -89,6 +89,49 @@ __global__ void k_c(const float4* __restrict__ src, float4* __restrict__ dst, si
     }
 }
 
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+// D: every thread moves UNR independent 16-byte pieces (all loads issued before the first store), one pass, no grid-stride loop
+template <int UNR, bool NT>
+__global__ __launch_bounds__(256) void k_d(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
+{
+    const size_t base = (size_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+    float4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n4) { if (NT) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src + i)); v[u] = make_float4(t.x, t.y, t.z, t.w); } else v[u] = src[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n4) { v[u].x += 1.0f; if (NT) { f4v t = {v[u].x, v[u].y, v[u].z, v[u].w}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(dst + i)); } else dst[i] = v[u]; }
+    }
+}
+// R: read only (sum kept so the loads stay), W: write only
+template <int UNR>
+__global__ __launch_bounds__(256) void k_r(const float4* __restrict__ src, float* __restrict__ sink, size_t n4)
+{
+    const size_t base = (size_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n4) { const float4 v = src[i]; acc += v.x + v.y + v.z + v.w; }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+template <int UNR>
+__global__ __launch_bounds__(256) void k_w(float4* __restrict__ dst, size_t n4)
+{
+    const size_t base = (size_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n4) dst[i] = make_float4(1.f, 2.f, 3.f, (float)u);
+    }
+}
+
 int main()
 {
     const int batch = 1024;
@@ -109,6 +152,16 @@ int main()
     time("A dword strips", [&] { hipLaunchKernelGGL(k_a, dim3(grid), dim3(256), 0, 0, a, b, batch); });
     time("B lds-dma x4 strips", [&] { hipLaunchKernelGGL(k_b, dim3(grid), dim3(256), 0, 0, a, b, batch); });
     time("C float4 copy", [&] { hipLaunchKernelGGL(k_c, dim3(2048), dim3(256), 0, 0, (const float4*)a, (float4*)b, n / 4); });
+
+    const size_t n4 = n / 4;
+    auto gridfor = [&](int unr) { return dim3((unsigned)((n4 + 256 * unr - 1) / (256 * unr))); };
+    time("D float4 copy unr4", [&] { hipLaunchKernelGGL((k_d<4, false>), gridfor(4), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4); });
+    time("D float4 copy unr8", [&] { hipLaunchKernelGGL((k_d<8, false>), gridfor(8), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4); });
+    time("D float4 copy unr8 nt", [&] { hipLaunchKernelGGL((k_d<8, true>), gridfor(8), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4); });
+    time("D float4 copy unr16", [&] { hipLaunchKernelGGL((k_d<16, false>), gridfor(16), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4); });
+    time("hipMemcpyAsync D2D", [&] { (void)hipMemcpyAsync(b, a, n * 4, hipMemcpyDeviceToDevice, 0); });
+    time("R read only unr8 (x2 = bytes)", [&] { hipLaunchKernelGGL((k_r<8>), gridfor(8), dim3(256), 0, 0, (const float4*)a, b, n4); });
+    time("W write only unr8 (x2 = bytes)", [&] { hipLaunchKernelGGL((k_w<8>), gridfor(8), dim3(256), 0, 0, (float4*)b, n4); });
     // correctness of B vs A
     std::vector<float> ha(ROWS * COLS), hb(ROWS * COLS);
     hipMemset(b, 0, n * 4);

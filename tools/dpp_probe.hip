@@ -10,6 +10,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
     const unsigned long long msk = 0x5555555555555555ull ^ (unsigned long long)blockIdx.x;
     const int mv = (threadIdx.x * 4) & 255;
     unsigned sc = blockIdx.x;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pa = {a, b}, pb = {c, d}, pc = {b, a}, pd = {d, c};
+    float e = 0.f, g = 0.f; int mvv = mv;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -32,10 +35,38 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
             if (MODE == 17) { asm volatile("v_max_f32 %0, %0, %1\n s_add_u32 %4, %4, 1\n v_max_f32 %1, %1, %2\n s_add_u32 %4, %4, 3\n v_max_f32 %2, %2, %3\n s_mul_i32 %4, %4, 5\n v_max_f32 %3, %3, %0\n s_add_u32 %4, %4, 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(sc)); }
             if (MODE == 18) { asm volatile("v_max_f32 %0, %0, %1\n s_nop 1\n v_max_f32_dpp %1, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_max_f32_dpp %2, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_max_f32_dpp %3, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
             if (MODE == 19) { asm volatile("v_max_f32 %0, %0, %1\n v_max_f32 %0, %0, %2\n v_max_f32 %0, %0, %3\n v_max_f32 %0, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+
+            if (MODE == 20) { asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %0" : "+v"(pa), "+v"(pb)); asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %0" : "+v"(pc), "+v"(pd)); }
+            if (MODE == 21) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %1, %1, %0, %0" : "+v"(pa), "+v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %1, %1, %0, %0" : "+v"(pc), "+v"(pd)); }
+            if (MODE == 22) { asm volatile("v_pk_mov_b32 %0, %1, %1\n v_pk_mov_b32 %1, %0, %0" : "+v"(pa), "+v"(pb)); asm volatile("v_pk_mov_b32 %0, %1, %1\n v_pk_mov_b32 %1, %0, %0" : "+v"(pc), "+v"(pd)); }
+            if (MODE == 23) { asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 24) { asm volatile("v_and_b32 %0, %0, %1\n v_or_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_and_b32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 25) { asm volatile("v_max_i32 %0, %0, %1\n v_max_i32 %1, %1, %2\n v_max_i32 %2, %2, %3\n v_max_i32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 26) { asm volatile("v_min_u32 %0, %0, %1\n v_min_u32 %1, %1, %2\n v_min_u32 %2, %2, %3\n v_min_u32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 27) { asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %0\n v_fma_f32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 28) { asm volatile("v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 29) { asm volatile("v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 30) { asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %3, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 31) { asm volatile("v_max_f32_e64 %0, %0, %1\n v_max_f32_e64 %1, %1, %2\n v_max_f32_e64 %2, %2, %3\n v_max_f32_e64 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 32) { asm volatile("v_min_f32 %0, %0, %1\n v_min_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_min_f32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 33) { asm volatile("v_maximum3_f32 %0, %0, %1, %2\n v_maximum3_f32 %1, %1, %2, %3\n v_minimum3_f32 %2, %2, %3, %0\n v_minimum3_f32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 34) { asm volatile("v_max3_i32 %0, %0, %1, %2\n v_med3_i32 %1, %1, %2, %3\n v_min3_u32 %2, %2, %3, %0\n v_med3_u32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 35) { asm volatile("v_pk_max_i16 %0, %0, %1\n v_pk_min_i16 %1, %1, %2\n v_pk_max_u16 %2, %2, %3\n v_pk_min_u16 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 36) { asm volatile("v_lshlrev_b32 %0, 1, %1\n v_lshrrev_b32 %1, 1, %2\n v_ashrrev_i32 %2, 1, %3\n v_lshlrev_b32 %3, 1, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 37) { asm volatile("v_sub_f32 %0, %0, %1\n v_sub_f32 %1, %1, %2\n v_subrev_f32 %2, %2, %3\n v_sub_f32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 38) { asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n v_bitop3_b32 %2, %2, %3, %0 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, %1 bitop3:0x96" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 39) { asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 40) { asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_i32 vcc, %1, %2\n v_cmp_eq_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0" :: "v"(a), "v"(b), "v"(c), "v"(d) : "vcc"); }
+            if (MODE == 41) { asm volatile("v_mul_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32_dpp %1, %2, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32_dpp %2, %3, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32_dpp %3, %0, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 42) { asm volatile("v_max_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_max_f32 %2, %2, %3\n v_add_f32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 43) { asm volatile("v_max_f32 %0, %0, %1\n v_max_f32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); asm volatile("ds_read_b32 %0, %1\n ds_read_b32 %2, %1 offset:256" : "=v"(e), "+v"(mvv), "=v"(g)); }
+            if (MODE == 44) { asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0" : "+v"(pa), "+v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0" : "+v"(pc), "+v"(pd)); }
+            if (MODE == 45) { asm volatile("v_cvt_f32_u32 %0, %1\n v_cvt_u32_f32 %1, %2\n v_cvt_f32_i32 %2, %3\n v_cvt_i32_f32 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (MODE == 46) { asm volatile("v_max_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_max_f32 %2, %2, %3\n v_max_f32 %3, %3, %0\n s_setprio 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
             if (MODE == 15) { asm volatile("v_max_u32 %0, %0, %1\n v_max_i32 %1, %1, %2\n v_min_u32 %2, %2, %3\n v_min_i32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + (float)sc;
+    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + (float)sc + pa.x + pa.y + pb.x + pb.y + pc.x + pd.y + e + g;
 }
 
 template <int MODE> void run(const char* name, float* d)
@@ -75,5 +106,33 @@ int main()
     run<17>("v_max + SALU alternating", d);
     run<18>("dependent DPP chain + s_nop 1", d);
     run<19>("dependent v_max chain", d);
+
+    run<20>("v_pk_add_f32 (2 flop/lane)", d);
+    run<21>("v_pk_fma_f32", d);
+    run<44>("v_pk_mul_f32", d);
+    run<22>("v_pk_mov_b32", d);
+    run<23>("v_add_u32", d);
+    run<24>("v_and/or/xor_b32", d);
+    run<25>("v_max_i32", d);
+    run<26>("v_min_u32", d);
+    run<27>("v_fma_f32", d);
+    run<28>("v_fmac_f32", d);
+    run<29>("v_add_f32_dpp wave_shr:1", d);
+    run<30>("v_mov_b32_dpp row_shr:1", d);
+    run<31>("v_max_f32_e64", d);
+    run<32>("v_min_f32", d);
+    run<33>("v_maximum3/minimum3_f32", d);
+    run<34>("v_max3/med3/min3 i32/u32", d);
+    run<35>("v_pk_max/min_i16/u16", d);
+    run<36>("shifts", d);
+    run<37>("v_sub_f32", d);
+    run<38>("v_bitop3_b32", d);
+    run<39>("v_permlane32/16_swap", d);
+    run<40>("v_cmp int -> vcc", d);
+    run<41>("v_mul_f32_dpp mixed", d);
+    run<42>("v_max_f32 / v_add_f32 alternating", d);
+    run<43>("2 v_max + 2 ds_read_b32", d);
+    run<45>("v_cvt", d);
+    run<46>("v_max x4 + s_setprio", d);
     return 0;
 }

@@ -1,6 +1,6 @@
-"""Rewrites the two merge networks of the time-shared 5x5 median (tools/median_shared_nets.h: MERGE55, MID20) with the
+"""Rewrites the two merge networks of the time-shared 5x5 median (depth_completion_mt_amd/csrc/median_shared_nets.h: MERGE55, MID20) with the
 three-input instructions gfx950 issues at the price of a two-input one (v_min3 / v_max3 / v_med3), and emits
-tools/median_shared_nets3.h.
+depth_completion_mt_amd/csrc/median_shared_nets3.h.
 
 A comparator network on SORTED inputs carries order knowledge a plain exchange does not use: with t = max(a, b) feeding an
 exchange against c,  min(t, c) = med3(a, b, c)  whenever c >= min(a, b), and  max(t, c) = max3(a, b, c)  always -- the
@@ -18,9 +18,12 @@ import itertools, os, random, re
 from collections import Counter
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# the headers live with the kernels that compile them; a copy of this script run from elsewhere (tests) works in its own directory
+_CSRC = os.path.join(HERE, "..", "depth_completion_mt_amd", "csrc")
+NETS = _CSRC if os.path.isfile(os.path.join(_CSRC, "median_shared_nets.h")) else HERE
 
 def read_net(name):
-    txt = open(os.path.join(HERE, "median_shared_nets.h")).read()
+    txt = open(os.path.join(NETS, "median_shared_nets.h")).read()
     body = re.search(r"#define DCMT_%s_NET\(CX, CMIN, CMAX\)(.*?)/\* end \*/" % name, txt, re.S).group(1)
     out = re.search(r"#define DCMT_%s_OUT \{([^}]*)\}" % name, txt).group(1)
     return body, [int(x) for x in out.split(",")]
@@ -160,7 +163,7 @@ def main():
         print(name, len(ops), "->", len(new), dict(Counter(o[0] for o in new)))
         hdr.append(f"/* {name}: {len(ops)} -> {len(new)} instructions */")
         hdr.append(emit(name, new, outs, len(outs)))
-    open(os.path.join(HERE, "median_shared_nets3.h"), "w").write("\n".join(hdr) + "\n")
+    open(os.path.join(NETS, "median_shared_nets3.h"), "w").write("\n".join(hdr) + "\n")
 
 if __name__ == "__main__":
     main()

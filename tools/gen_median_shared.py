@@ -1,4 +1,5 @@
-"""Generates tools/median_shared_nets.h: the comparator networks of the time-shared exact
+"""Generates median_shared_nets.h in the current directory (checked in as depth_completion_mt_amd/csrc/median_shared_nets.h
+for the kernels and, with its own header comment, as oracle/median_nets.h for the CPU oracle): the comparator networks of the time-shared exact
 5x5 median used by the streaming post kernel, and verifies them.
 
 Scheme (per lane = per image column, rows arrive one per step):
