@@ -76,6 +76,27 @@ constexpr int FTH_FEW = 16;          // tile height of the staged kernels for a 
         }                                                          \
     } while (0)
 
+
+// Every entry point that takes a context runs with that context's device current and puts the caller's current device back
+// before it returns: one process may drive several GPUs, one host thread + one dcmt_ctx + one stream per GPU (HIP's current
+// device is per thread), and a library that is shared with a framework (torch) must not move that framework's device.
+struct DeviceGuard {
+    int prev = -1, rc = DCMT_OK;
+    explicit DeviceGuard(dcmt_ctx* ctx)
+    {
+        if (!ctx) return;                                   // the entry point reports DCMT_E_INVALID itself
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; rc = DCMT_E_HIP; return; }
+        if (prev != ctx->device) {
+            const hipError_t e = hipSetDevice(ctx->device);
+            if (e != hipSuccess) { ctx->last_hip_error = (int)e; rc = DCMT_E_HIP; prev = -1; }
+        } else prev = -1;                                   // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DCMT_ON_DEVICE(ctx) DeviceGuard dev_guard_(ctx); if (dev_guard_.rc != DCMT_OK) return dev_guard_.rc
+
 uint32_t k0_bits(const uint8_t k0[25])
 {
     uint32_t b = 0;
@@ -453,7 +474,6 @@ int host_call(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int
     if (rc != DCMT_OK) return rc;
     if (srs < sizeof(float) * (size_t)cols || drs < sizeof(float) * (size_t)cols) return DCMT_E_INVALID;
     if (labels && lrs < sizeof(int32_t) * (size_t)cols) return DCMT_E_INVALID;
-    DCMT_HIP(ctx, hipSetDevice(ctx->device));
     rc = ensure_host_staging(ctx, labels != nullptr);
     if (rc != DCMT_OK) return rc;
     hipStream_t st = ctx->own_stream;
@@ -545,7 +565,9 @@ void dcmt_default_params(dcmt_params* p)
 int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx** out)
 {
     if (!out || max_rows < 1 || max_cols < 1 || max_batch < 1 || max_batch > 65535) return DCMT_E_INVALID;
-    if ((size_t)max_rows * (size_t)max_cols > (size_t)0x1fffffff) return DCMT_E_INVALID;   // a frame is addressed with 32-bit byte offsets
+    // a frame is one raw buffer resource addressed with 32-bit byte offsets, and kDropOffset (dcmt_kernels_fused.h) must lie
+    // beyond its last byte for the "store that writes nothing" idiom: frame bytes <= 0x7fffffc0
+    if ((size_t)max_rows * (size_t)max_cols > (size_t)0x1ffffff0) return DCMT_E_INVALID;
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return DCMT_E_NO_DEVICE;
@@ -565,8 +587,9 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
     { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
     { const char* e = std::getenv("DCMT_LABEL_PAIRS"); if (e) ctx->label_pairs = std::atoi(e); }
+    DeviceGuard dev_guard_(ctx);                    // allocate on the context's device, leave the caller's current device as it was
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
-    if (hipSetDevice(device) != hipSuccess) return fail(DCMT_E_HIP);
+    if (dev_guard_.rc != DCMT_OK) return fail(dev_guard_.rc);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;
     if (hipMalloc((void**)&ctx->x5, plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[0], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
@@ -584,7 +607,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
 void dcmt_destroy(dcmt_ctx* ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard dev_guard_(ctx);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
     (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters);
@@ -600,6 +623,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
 int dcmt_complete_f32(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, float* dst, size_t drs, size_t dfs,
                       int rows, int cols, int batch, const dcmt_params* params)
 {
+    DCMT_ON_DEVICE(ctx);
     return host_call(ctx, src, srs, sfs, nullptr, 0, 0, 0, 0, dst, drs, dfs, rows, cols, batch, params, false);
 }
 
@@ -607,6 +631,7 @@ int dcmt_complete_labeled_f32(dcmt_ctx* ctx, const float* src, size_t srs, size_
                               size_t lfs, int n_labels, float* dst, size_t drs, size_t dfs, int rows, int cols, int batch,
                               const dcmt_params* params, int use_superpixel)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!labels) return DCMT_E_INVALID;
     return host_call(ctx, src, srs, sfs, labels, lrs, lfs, n_labels, use_superpixel, dst, drs, dfs, rows, cols, batch,
                      params, true);
@@ -615,6 +640,7 @@ int dcmt_complete_labeled_f32(dcmt_ctx* ctx, const float* src, size_t srs, size_
 int dcmt_complete_f32_dev(dcmt_ctx* ctx, const float* d_src, float* d_dst, int rows, int cols, int batch,
                           const dcmt_params* params, void* stream)
 {
+    DCMT_ON_DEVICE(ctx);
     int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
     if (rc != DCMT_OK) return rc;
     return run_chain(ctx, d_src, nullptr, 0, 0, d_dst, rows, cols, batch, params, false, (hipStream_t)stream, false);
@@ -623,6 +649,7 @@ int dcmt_complete_f32_dev(dcmt_ctx* ctx, const float* d_src, float* d_dst, int r
 int dcmt_complete_u16_dev(dcmt_ctx* ctx, const uint16_t* d_src, float scale, float* d_dst, int rows, int cols, int batch,
                           const dcmt_params* params, void* stream)
 {
+    DCMT_ON_DEVICE(ctx);
     int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
     if (rc != DCMT_OK) return rc;
     return run_chain(ctx, nullptr, nullptr, 0, 0, d_dst, rows, cols, batch, params, false, (hipStream_t)stream, false, d_src, scale);
@@ -631,6 +658,7 @@ int dcmt_complete_u16_dev(dcmt_ctx* ctx, const uint16_t* d_src, float scale, flo
 int dcmt_complete_labeled_f32_dev(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_labels, float* d_dst,
                                   int rows, int cols, int batch, const dcmt_params* params, int use_superpixel, void* stream)
 {
+    DCMT_ON_DEVICE(ctx);
     int rc = check_params(ctx, d_src, d_dst, rows, cols, batch, params);
     if (rc != DCMT_OK) return rc;
     if (!d_labels) return DCMT_E_INVALID;
@@ -641,6 +669,7 @@ int dcmt_complete_labeled_f32_dev(dcmt_ctx* ctx, const float* d_src, const int32
 int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t* d_offsets, int n_points, int batch,
                             const float T[16], const float P[12], float* d_sparse, int rows, int cols, void* stream)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !d_offsets || !T || !P || !d_sparse || n_points < 0 || (n_points > 0 && !d_points)) return DCMT_E_INVALID;
     if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
@@ -672,6 +701,7 @@ void dcmt_default_stereo_params(dcmt_stereo_params* p)
 int dcmt_stereo_refine_dev(dcmt_ctx* ctx, const float* d_depth, const uint8_t* d_left, const uint8_t* d_right, float* d_refined,
                            int rows, int cols, int batch, const dcmt_stereo_params* params, void* stream)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !d_depth || !d_left || !d_right || !d_refined || !params) return DCMT_E_INVALID;
     if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
     if (params->iterations > 1000) return DCMT_E_INVALID;
@@ -696,6 +726,7 @@ int dcmt_slic_num_centers(int rows, int cols, int step)
 int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols, int batch, int step, int nc,
                          int32_t* d_labels, double* d_centers, void* stream)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !d_lab || !d_labels) return DCMT_E_INVALID;
     if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
     if (step < 6 || nc < 1) return DCMT_E_INVALID;
@@ -703,7 +734,6 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     hipStream_t st = (hipStream_t)stream;
     const size_t px = (size_t)batch * rows * cols;
     if (n == 0) { DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st)); return DCMT_OK; }
-    DCMT_HIP(ctx, hipSetDevice(ctx->device));
     int cell_px = step;                                                    // cells of step x step pixels
     { const char* e = std::getenv("DCMT_SLIC_CELL_SCALE"); if (e && std::atoi(e) > 1) cell_px = step * std::atoi(e); }   // tests: crowded cells
     const int gx = (cols - 1) / cell_px + 1, gy = (rows - 1) / cell_px + 1;
@@ -752,7 +782,6 @@ struct DevBuf {                                    // freed when the call return
 };
 int host_stream(dcmt_ctx* ctx, hipStream_t* st)
 {
-    DCMT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->own_stream) DCMT_HIP(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     *st = ctx->own_stream;
     return DCMT_OK;
@@ -762,6 +791,7 @@ int host_stream(dcmt_ctx* ctx, hipStream_t* st)
 int dcmt_project_points(dcmt_ctx* ctx, const float* points, int n_points, const float T[16], const float P[12],
                         float* sparse, size_t srs, int rows, int cols)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !sparse || !T || !P || n_points < 0 || (n_points > 0 && !points) || rows < 1 || cols < 1) return DCMT_E_INVALID;
     if (srs < sizeof(float) * (size_t)cols) return DCMT_E_INVALID;
     hipStream_t st;
@@ -783,6 +813,7 @@ int dcmt_project_points(dcmt_ctx* ctx, const float* points, int n_points, const 
 
 int dcmt_slic_labels(dcmt_ctx* ctx, const uint8_t* lab, size_t lrs, int rows, int cols, int step, int nc, int32_t* labels, double* centers)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !lab || !labels || rows < 1 || cols < 1 || lrs < 3 * (size_t)cols) return DCMT_E_INVALID;
     hipStream_t st;
     int rc = host_stream(ctx, &st);
@@ -804,6 +835,7 @@ int dcmt_slic_labels(dcmt_ctx* ctx, const uint8_t* lab, size_t lrs, int rows, in
 int dcmt_stereo_refine(dcmt_ctx* ctx, const float* depth, size_t drs, const uint8_t* left, size_t lrs, const uint8_t* right, size_t rrs,
                        float* refined, size_t ors, int rows, int cols, const dcmt_stereo_params* params)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !depth || !left || !right || !refined || !params || rows < 1 || cols < 1) return DCMT_E_INVALID;
     if (drs < sizeof(float) * (size_t)cols || ors < sizeof(float) * (size_t)cols || lrs < (size_t)cols || rrs < (size_t)cols) return DCMT_E_INVALID;
     hipStream_t st;
@@ -825,7 +857,6 @@ int dcmt_stereo_refine(dcmt_ctx* ctx, const float* depth, size_t drs, const uint
 
 static int read_counters(dcmt_ctx* ctx)
 {
-    DCMT_HIP(ctx, hipSetDevice(ctx->device));
     DCMT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(int) * (size_t)ctx->last_batch * kCntStride,
                                  hipMemcpyDeviceToHost, ctx->last_stream));
     DCMT_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
@@ -834,6 +865,7 @@ static int read_counters(dcmt_ctx* ctx)
 
 int dcmt_last_fill_iters(dcmt_ctx* ctx, int* out, int n)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !out || n < 0 || n > ctx->last_batch) return DCMT_E_INVALID;
     if (!ctx->last_has_loop) return DCMT_E_INVALID;
     int rc = read_counters(ctx);
@@ -850,6 +882,7 @@ int dcmt_last_fill_iters(dcmt_ctx* ctx, int* out, int n)
 
 int dcmt_last_holes_after_extend(dcmt_ctx* ctx, int* out, int n)
 {
+    DCMT_ON_DEVICE(ctx);
     if (!ctx || !out || n < 0 || n > ctx->last_batch) return DCMT_E_INVALID;
     int rc = read_counters(ctx);
     if (rc != DCMT_OK) return rc;

@@ -47,6 +47,12 @@ __device__ __forceinline__ float hgrow_min(float w) { const float l = from_left(
 // byte offset in an SGPR) -- buffer_load_dword v, v_off, s[rsrc], s_row offen -- so a row access costs no VALU
 // address arithmetic at all (a flat global access spends one 64-bit per-lane add per row) and the lane offsets need
 // one VGPR each instead of a 64-bit pointer pair.  Raw buffer, stride 0, num_records = the frame's bytes.
+// A store every lane issues on every step but that must write nothing (halo lanes, steps without an output row) is aimed
+// at kDropOffset.  Rule relied on (CDNA3/4 ISA, buffer instructions, "range checking"): for a raw buffer (stride 0, no
+// swizzle) an access is out of range when voffset + inst_offset + access size > num_records -- the SGPR offset is NOT part
+// of the check -- and an out-of-range store is dropped (a load returns 0).  dcmt_create admits frames of at most
+// 0x1ffffff0 pixels, so num_records = frame bytes <= 0x7fffffc0 < kDropOffset for every frame this library accepts.
+constexpr unsigned kDropOffset = 0x7ffffff0u;
 struct FrameBuf {
     __amdgpu_buffer_rsrc_t rs;
     __device__ __forceinline__ void init(const float* frame, size_t elems)
@@ -335,7 +341,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // rows above the first valid one are written by the epilogue.  The store instruction itself is issued on every step
             // by every lane (the DMA waits above count on it): lanes and steps with nothing to write aim past the end of the
             // buffer resource, where the hardware drops the write
-            ob.st((inrows && outlane && m >= ti) ? oc : 0x7ffffff0u, inrows ? m : 0, cols, x5);
+            ob.st((inrows && outlane && m >= ti) ? oc : kDropOffset, inrows ? m : 0, cols, x5);
         }
     }
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
@@ -499,7 +505,7 @@ __device__ __forceinline__ void label_pipeline(const FrameBuf& sb, const FrameBu
             const float e4 = fmin3(fmin3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
             // write-back only where the label is this one (LC :101)
             // every lane stores on every step (exact load waits); the ones with nothing to write aim past the buffer (dropped)
-            ob.st_at((l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) ? gb + 4u * (unsigned)(l * cols) : 0x7ffffff0u, e4);
+            ob.st_at((l >= y0 && l <= y1 && outlane && LB[(p + 2) & 7] == L) ? gb + 4u * (unsigned)(l * cols) : kDropOffset, e4);
         }
     }
 }
@@ -658,7 +664,7 @@ struct PostPipe {
                     if (mo >= thr) val = acc;                           // LO :184
                 }
                 if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
-                of.st(outlane ? ob : 0x7ffffff0u, o, cols, val);     // every lane stores; halo lanes aim past the buffer (dropped)
+                of.st(outlane ? ob : kDropOffset, o, cols, val);     // every lane stores; halo lanes aim past the buffer (dropped)
             };
             const float g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7];
             const float g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];

@@ -17,6 +17,19 @@
  * function returns DCMT_OK (0) or a negative dcmt_status.  A dcmt_ctx is bound to one
  * GPU and owns all scratch memory; it must not be used from two threads at once (one ctx
  * per GPU per host thread -- frames are independent, so multi-GPU is one ctx per device).
+ *
+ * Devices and threads: every entry point that takes a ctx makes ctx's device current for the
+ * duration of the call and restores the calling thread's current device before it returns, so
+ * one process may drive all GPUs of a node from one host thread per GPU (or from one thread,
+ * ctx after ctx) without ever calling hipSetDevice itself.  Device pointers and the stream
+ * passed to a *_dev entry point must belong to ctx's device; stream == NULL is that device's
+ * default stream.
+ *
+ * Values: frames must be finite (no NaN, no +-Inf).  The library is built with
+ * -ffinite-math-only (its max/min networks drop the NaN-quieting pass), so a NaN or Inf in an
+ * input frame gives an unspecified (but memory-safe) result in the pixels its windows reach.
+ * The reference's own result for such pixels depends on the min/max flavour of the OpenCV
+ * build (SIMD vs scalar), so there is nothing to be bit-exact with.  -0.0 is treated as 0.0.
  */
 #ifndef DCMT_H
 #define DCMT_H

@@ -3,6 +3,16 @@
 // main_lc.cpp:220 calls interpolate_with_superpixels.  Reads raw f32/int32 files written by the
 // pytest driver, writes raw f32 results; the driver compares them with the oracle.
 //   shim_test <rows> <cols> <in.f32> <out.f32> [labels.i32 n_labels out_lc.f32 [out_norm100.f32 out_lc_norm80.f32]]
+// Stand-in for the reference's Slic (src/DC_lidar_camera/slic.h:30-40): only the two public members the reference's
+// interpolate_with_superpixels reads -- clusters[col][row] (:83) and centers.size() (:78).  With it and DCMT_WITH_SLIC
+// the header below compiles the reference's exact signature (img_completion_lc.cpp:34-38), called further down.
+#include <vector>
+class Slic {
+public:
+    std::vector<std::vector<int> > clusters;        // [col][row]
+    std::vector<std::vector<double> > centers;      // one (L, a, b, x, y) row per centre
+};
+#define DCMT_WITH_SLIC
 #include "img_completion.h"
 
 #include <cstdio>
@@ -59,6 +69,23 @@ int main(int argc, char** argv)
         dcmt_shim::interpolate_with_labels(clusters, n_labels, sparse, dense_sp, "gaussian", 1);
         for (int r = 0; r < rows; ++r) std::memcpy(&out[(size_t)r * cols], dense_sp.ptr<float>(r), (size_t)cols * 4);
         if (!write_all(argv[7], out.data(), out.size() * 4)) return 9;
+        {
+            // the reference's own overload, as main_lc.cpp:220 calls it: interpolate_with_superpixels(slic, sparse, dense_sp, "gaussian", 1)
+            Slic slic;
+            slic.clusters = clusters;
+            slic.centers.assign((size_t)n_labels, std::vector<double>(5, 0.0));
+            cv::Mat dense_ref;
+            interpolate_with_superpixels(slic, sparse, dense_ref, "gaussian", 1);
+            if (dense_ref.rows != rows || dense_ref.cols != cols) return 20;
+            for (int r = 0; r < rows; ++r)
+                if (std::memcmp(dense_ref.ptr<float>(r), dense_sp.ptr<float>(r), (size_t)cols * 4) != 0) return 21;
+            // use_superpixel == 0 (img_completion_lc.cpp:59-64): the plain first stage, Gaussian unconditional
+            cv::Mat dense_nosp, dense_plain;
+            interpolate_with_superpixels(slic, sparse, dense_nosp, "none", 0);
+            img_completion(sparse, dense_plain, false, "gaussian");
+            for (int r = 0; r < rows; ++r)
+                if (std::memcmp(dense_nosp.ptr<float>(r), dense_plain.ptr<float>(r), (size_t)cols * 4) != 0) return 22;
+        }
         if (argc >= 10) {
             // the stereo-lidar callers: cv::normalize(..., 0, 100) + img_completion (main_sl.cpp:370, :386) and
             // cv::normalize(..., 0, 80) + interpolate_with_superpixels (:523, :540), each as one fused call

@@ -65,6 +65,9 @@ def test_null_and_range_validation_without_gpu():
     assert lib.dcmt_create(0, 0, 10, 1, ctypes.byref(h)) == L.E_INVALID
     assert lib.dcmt_create(0, 10, 10, 1, None) == L.E_INVALID
     assert lib.dcmt_create(0, 1 << 15, 1 << 15, 1, ctypes.byref(h)) == L.E_INVALID     # 2^30 pixels: beyond 32-bit byte offsets
+    # the "store that writes nothing" offset (kDropOffset = 0x7ffffff0, dcmt_kernels_fused.h) must lie beyond every admitted frame:
+    # 0x1ffffff1 pixels = 0x7fffffc4 bytes is refused (the limit is 0x1ffffff0 pixels)
+    assert lib.dcmt_create(0, 1, 0x1ffffff1, 1, ctypes.byref(h)) == L.E_INVALID
     assert lib.dcmt_slic_num_centers(352, 1216, 18) == 67 * 19 and lib.dcmt_slic_num_centers(375, 1242, 68) == 17 * 5
     assert lib.dcmt_slic_labels_dev(None, None, 8, 8, 1, 6, 1, None, None, None) == L.E_INVALID
     assert lib.dcmt_project_points_dev(None, None, None, 0, 1, None, None, None, 8, 8, None) == L.E_INVALID

@@ -46,6 +46,28 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
             if (MODE == 24) asm volatile("v_max_f32 %0, %0, %1\n v_fma_f32 %4, %4, %5, %6\n v_max_f32 %1, %1, %2\n v_fma_f32 %5, %5, %6, %7" OPS8);                                 // 2S 2F(fma)
             if (MODE == 25) asm volatile("v_max_f32 %0, %0, %1\n v_mov_b32 %4, %5\n v_max_f32 %1, %1, %2\n v_mov_b32 %5, %6" OPS8);                                               // 2S 2F(mov)
             if (MODE == 26) asm volatile("v_sub_f32 %4, %0, %1\n v_ashrrev_i32 %4, 31, %4\n v_bitop3_b32 %0, %4, %1, %0 bitop3:0xca\n v_sub_f32 %5, %2, %3\n v_ashrrev_i32 %5, 31, %5\n v_bitop3_b32 %2, %5, %3, %2 bitop3:0xca" OPS8);   // select by sign: 2 x (F, ?, F)
+
+            if (MODE == 30) asm volatile("v_max_f32 %0, %0, %1\n v_xor_b32 %4, %4, %5\n v_max_f32 %1, %1, %2\n v_xor_b32 %5, %5, %6" OPS8);
+            if (MODE == 31) asm volatile("v_med3_f32 %0, %0, %1, %2\n v_add_f32 %4, %4, %5\n v_med3_f32 %1, %1, %2, %3\n v_add_f32 %5, %5, %6" OPS8);
+            if (MODE == 32) asm volatile("v_max_f32 %0, %0, %1\n v_bitop3_b32 %4, %4, %5, %6 bitop3:0x96\n v_max_f32 %1, %1, %2\n v_bitop3_b32 %5, %5, %6, %7 bitop3:0x96" OPS8);
+            if (MODE == 33) asm volatile("v_min_f32 %4, %0, %1\n v_xor_b32 %5, %0, %1\n v_xor_b32 %5, %5, %4\n v_min_f32 %6, %2, %3\n v_xor_b32 %7, %2, %3\n v_xor_b32 %7, %7, %6\n"
+                                         "v_min_f32 %0, %4, %6\n v_xor_b32 %2, %4, %6\n v_xor_b32 %2, %2, %0\n v_min_f32 %1, %5, %7\n v_xor_b32 %3, %5, %7\n v_xor_b32 %3, %3, %1" OPS8);   // 4 CE = 4S + 8F (VOP2 only)
+            if (MODE == 34) asm volatile("v_max3_f32 %0, %0, %1, %2\n v_add_f32 %4, %4, %5\n v_max3_f32 %1, %1, %2, %3\n v_add_f32 %5, %5, %6" OPS8);
+            if (MODE == 35) asm volatile("v_max_f32 %0, %0, %1\n v_and_b32 %4, %4, %5\n v_max_f32 %1, %1, %2\n v_or_b32 %5, %5, %6" OPS8);
+            if (MODE == 36) asm volatile("v_max_f32 %0, %0, %1\n v_add_u32 %4, %4, %5\n v_max_f32 %1, %1, %2\n v_add_u32 %5, %5, %6" OPS8);
+            if (MODE == 37) asm volatile("v_max_f32 %0, %0, %1\n v_mul_f32 %4, %4, %5\n v_max_f32 %1, %1, %2\n v_sub_f32 %5, %5, %6" OPS8);
+            if (MODE == 38) asm volatile("v_min_f32 %4, %0, %1\n v_add_f32 %5, %4, %1\n v_min_f32 %6, %2, %3\n v_add_f32 %7, %6, %3\n v_min_f32 %0, %5, %7\n v_add_f32 %1, %0, %4\n v_min_f32 %2, %1, %6\n v_add_f32 %3, %2, %5" OPS8);   // 4S 4F, each add depends on the min before it
+            if (MODE == 39) asm volatile("v_max_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32 %4, %5\n v_max_f32_dpp %1, %2, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32 %5, %6" OPS8);
+            if (MODE == 40) asm volatile("v_xor_b32 %4, %4, %5\n v_xor_b32 %5, %5, %6\n v_xor_b32 %6, %6, %7\n v_xor_b32 %7, %7, %4" OPS8);
+            if (MODE == 41) asm volatile("v_bitop3_b32 %4, %4, %5, %6 bitop3:0x96\n v_bitop3_b32 %5, %5, %6, %7 bitop3:0x96\n v_bitop3_b32 %6, %6, %7, %4 bitop3:0x96\n v_bitop3_b32 %7, %7, %4, %5 bitop3:0x96" OPS8);
+            if (MODE == 42) asm volatile("v_med3_f32 %0, %0, %1, %2\n v_mov_b32 %4, %5\n v_med3_f32 %1, %1, %2, %3\n v_mov_b32 %5, %6" OPS8);
+            if (MODE == 43) asm volatile("v_max_f32_e64 %0, %0, %1\n v_add_f32 %4, %4, %5\n v_max_f32_e64 %1, %1, %2\n v_add_f32 %5, %5, %6" OPS8);
+            if (MODE == 44) asm volatile("v_med3_f32 %0, %0, %1, %2\n v_fma_f32 %4, %4, %5, %6\n v_med3_f32 %1, %1, %2, %3\n v_fma_f32 %5, %5, %6, %7" OPS8);
+            if (MODE == 45) asm volatile("v_min_f32 %4, %0, %1\n v_max_f32 %5, %0, %1\n v_add_f32 %6, %6, %7\n v_min_f32 %0, %4, %2\n v_max_f32 %2, %4, %2\n v_add_f32 %7, %7, %6" OPS8);   // 4S 2F
+            if (MODE == 46) asm volatile("v_max_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_add_f32 %4, %4, %5\n v_add_f32 %5, %5, %6" OPS8);   // 2S then 2F (not alternating)
+            if (MODE == 47) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_max_f32 %4, %4, %5\n v_mov_b32_dpp %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_max_f32 %5, %5, %6" OPS8);   // dpp mov + plain max
+            if (MODE == 48) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %4, %4, %5, vcc\n v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %5, %5, %6, vcc" OPS8 :: "vcc");
+            if (MODE == 49) asm volatile("v_max_f32 %0, %0, %1\n v_lshrrev_b32 %4, 1, %5\n v_max_f32 %1, %1, %2\n v_ashrrev_i32 %5, 1, %6" OPS8);
             if (MODE == 27) asm volatile("v_cvt_f32_ubyte0 %0, %1\n v_cvt_f32_ubyte1 %1, %2\n v_cvt_f32_ubyte2 %2, %3\n v_cvt_f32_ubyte3 %3, %0" OPS8);
             if (MODE == 28) asm volatile("v_max_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_max_f32 %2, %2, %3\n v_max_f32 %3, %3, %0\n s_nop 3" OPS8);
             if (MODE == 29) asm volatile("v_add_f32 %4, %4, %5\n v_add_f32 %5, %5, %6\n v_add_f32 %6, %6, %7\n v_add_f32 %7, %7, %4\n s_nop 3" OPS8);
@@ -92,12 +114,18 @@ int main()
         {"2 v_max_dpp + 2 v_add", 4}, {"2 v_med3 + 2 v_xor", 4}, {"2 v_cndmask(sgpr) + 2 v_add", 4}, {"2 v_mov_dpp + 2 v_add", 4}, {"4 v_perm_b32", 4},
         {"4 v_alignbit_b32", 4}, {"v_and_or / v_or3", 4}, {"v_add3_u32 / v_lshl_add_u32", 4}, {"v_mad_u32_u24 / v_mul_u32_u24", 4}, {"v_sub_u32 / v_not", 4},
         {"4 v_mul_lo_u32", 4}, {"2 v_cmp + 2 v_add", 4}, {"2 v_max3 + 4 v_xor", 6}, {"2 v_max + 2 v_fma", 4}, {"2 v_max + 2 v_mov", 4},
-        {"2 x (v_sub, v_ashrrev 31, bitop3 select)", 6}, {"4 v_cvt_f32_ubyteN", 4}, {"4 v_max + s_nop 3", 4}, {"4 v_add + s_nop 3", 4}};
+        {"2 x (v_sub, v_ashrrev 31, bitop3 select)", 6}, {"4 v_cvt_f32_ubyteN", 4}, {"4 v_max + s_nop 3", 4}, {"4 v_add + s_nop 3", 4},
+        {"2 v_max + 2 v_xor", 4}, {"2 v_med3 + 2 v_add", 4}, {"2 v_max + 2 v_bitop3", 4}, {"network: 4 (v_min + 2 dependent v_xor)", 12}, {"2 v_max3 + 2 v_add", 4},
+        {"2 v_max + v_and + v_or", 4}, {"2 v_max + 2 v_add_u32", 4}, {"2 v_max + v_mul + v_sub", 4}, {"4 x (v_min, dependent v_add)", 8}, {"2 v_max_dpp + 2 v_mov", 4},
+        {"4 v_xor", 4}, {"4 v_bitop3", 4}, {"2 v_med3 + 2 v_mov", 4}, {"2 v_max_e64 + 2 v_add", 4}, {"2 v_med3 + 2 v_fma", 4}, {"4 S (min/max pairs) + 2 v_add", 6},
+        {"2 v_max, then 2 v_add", 4}, {"2 v_mov_dpp + 2 v_max", 4}, {"2 x (v_cmp, v_cndmask vcc)", 4}, {"2 v_max + v_lshr + v_ashr", 4}};
 #define RUN(I, W) run<I>(M[I], d, W)
 #define ALLW(I) RUN(I, 8); RUN(I, 2); RUN(I, 1)
     ALLW(0); ALLW(1); ALLW(2); ALLW(3); ALLW(4); ALLW(5); ALLW(6); ALLW(7);
     RUN(8, 8); RUN(9, 8); RUN(10, 8); RUN(11, 8); RUN(12, 8); RUN(13, 8); RUN(14, 8); RUN(15, 8); RUN(16, 8); RUN(17, 8); RUN(18, 8); RUN(19, 8);
     RUN(20, 8); RUN(21, 8); RUN(22, 8); RUN(23, 8); RUN(24, 8); RUN(25, 8); RUN(26, 8); RUN(27, 8); RUN(28, 8); RUN(29, 8);
+    RUN(30, 8); RUN(31, 8); RUN(32, 8); RUN(33, 8); RUN(34, 8); RUN(35, 8); RUN(36, 8); RUN(37, 8); RUN(38, 8); RUN(39, 8); RUN(40, 8); RUN(41, 8);
+    RUN(42, 8); RUN(43, 8); RUN(44, 8); RUN(45, 8); RUN(46, 8); RUN(47, 8); RUN(48, 8); RUN(49, 8); RUN(33, 4); RUN(38, 4); RUN(45, 4); RUN(7, 4);
     unsigned* u; (void)hipMalloc(&u, 16);
     hipLaunchKernelGGL(k_denorm, dim3(1), dim3(1), 0, 0, u);
     unsigned hu[4]; (void)hipMemcpy(hu, u, 16, hipMemcpyDeviceToHost);
