@@ -29,6 +29,7 @@ struct dcmt_ctx {
     float* pp[2] = {nullptr, nullptr};// ping-pong of the large-fill applications
     int* colstat = nullptr;           // [max_batch][tile rows][2][cols]  (staged path)
     int* counters = nullptr;          // [max_batch][kCntStride]
+    int* tcol = nullptr;              // [max_batch][max_cols]: first valid row of every X6 column (k_pre_s table mode -> k_fp_s)
     uint32_t* norm_stats = nullptr;   // [max_batch][2]  N1: order-preserving keys of each frame's max and (inverted) min
     float* norm_coef = nullptr;       // [max_batch][2]  N1: dst = src * a + b
     // host-entry staging (allocated on first use)
@@ -48,6 +49,7 @@ struct dcmt_ctx {
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
     int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
     int fuse_fp = 1;                  // H7..H11 in one kernel (k_fp_s); env DCMT_FUSE_FP=0 keeps k_fill_s + k_post_s
+    int top_table = 1;                // k_pre_s leaves the top extension zone of X6 unwritten, k_fp_s starts below it; env DCMT_TOP_TABLE=0 disables
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
@@ -214,6 +216,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         float* pp1 = ctx->pp[1] + f0 * fe;
         int* cnt = ctx->counters + (size_t)f0 * kCntStride;
         const float* cf = coef ? coef + 2 * (size_t)f0 : nullptr;
+        // table mode: only the k_fp_s path reads X6 through the per-column table (the probes and the unfused kernels get a fully written X6)
+        int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tcol + (size_t)f0 * cols : nullptr;
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
             // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
@@ -221,13 +225,13 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr;
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
                 if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
-                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr); \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); \
                 else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src16, o6, \
-                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr); \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc); \
                 else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
-                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf); \
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
                 else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
-                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr); }
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); }
             if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
             else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
 #undef DCMT_PRE
@@ -242,8 +246,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
             // k_fp_s deals (frame, strip) pairs to waves in one flat sequence (per XCD with the XCD map): no half-empty workgroups
             const dim3 fpg = wave_grid(pstrips, nb, xm);
-            if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
-            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh);
+            if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc);
+            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc);
             DCMT_HIP(ctx, hipGetLastError());
             ctx->last_has_loop = 1;
             const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);
@@ -255,11 +259,11 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     for (int f = 0; f < batch; ++f) any |= ctx->h_counters[(size_t)f * kCntStride + 1] > 0;
                     if (!any) { if (p->verbose) for (int f = 0; f < batch; ++f) std::printf("0\n"); continue; }
                 }
-                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1);
+                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1, (const int*)tc);
                 int apps = 0;
                 const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
                     hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                                       fstrips, nb, xm, p->valid_thresh, i, 0);
+                                       fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr);
                 }, &apps);
                 if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
                 if (lrc != DCMT_OK) rc = lrc;
@@ -271,7 +275,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             continue;
         }
         hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
-                           fstrips, nb, xm, p->valid_thresh, 0, 0);
+                           fstrips, nb, xm, p->valid_thresh, 0, 0, (const int*)nullptr);
         DCMT_HIP(ctx, hipGetLastError());
         if (stop == DCMT_STAGE_FILL31) continue;
 
@@ -279,7 +283,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         int apps = 0;
         const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
             hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                               fstrips, nb, xm, p->valid_thresh, i, 0);
+                               fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr);
         }, &apps);
         if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
         if (lrc != DCMT_OK) rc = lrc;
@@ -585,6 +589,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_XCD_MAP"); if (e) ctx->xcd_map = std::atoi(e); }
     { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
     { const char* e = std::getenv("DCMT_LABEL_PAIRS"); if (e) ctx->label_pairs = std::atoi(e); }
     DeviceGuard dev_guard_(ctx);                    // allocate on the context's device, leave the caller's current device as it was
@@ -596,6 +601,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + FTH_FEW - 1) / FTH_FEW) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->tcol, sizeof(int) * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->h_counters, sizeof(int) * (size_t)kCntStride * max_batch, hipHostMallocDefault) != hipSuccess)
@@ -610,7 +616,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     DeviceGuard dev_guard_(ctx);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
-    (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters);
+    (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters); (void)hipFree(ctx->tcol);
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
     (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);

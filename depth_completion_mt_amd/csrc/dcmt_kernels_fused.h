@@ -206,7 +206,8 @@ struct PreS {
 template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false, bool NORM = false>
 __global__ __launch_bounds__(256)
 void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips,
-             int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef)
+             int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
+             int* __restrict__ tcol)
 {
     static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
@@ -255,19 +256,58 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 #define DCMT_PRE_PFD 4
 #endif
     constexpr int PFD = DCMT_PRE_PFD;            // rows of load lookahead (dword path)
-    if constexpr (WIDE) {
+
+    // ---- leading empty rows (the upper third of a velodyne frame): nothing to compute there.  x5(m, c) can only be valid
+    // (>= thr) if some input pixel within the chain's reach -- rows m-9 .. m+9 -- is valid: maxima and minima of values
+    // below thr (the -FLT_MAX dilate border included; the erode's +FLT_MAX border never wins against an in-image row) stay
+    // below thr.  So with zv = the first row in which any of this wave's columns holds a valid value, every x5 row above
+    // zv - 9 is invalid: it is neither stored (rows above the column's first valid row belong to H6) nor counted.  The stream
+    // starts at row S <= zv - 18 with cold rings; x5 rows from S + 9 on see only rings filled from real rows (reach 9), the
+    // rows before are discarded (m0).  S is a multiple of 8 so that the ring phases stay compile-time.
+    int S = 0;
+    if constexpr (!START4) {
+        auto valid16 = [&](const float (&v)[16]) -> bool {
+            float m = fmax3(fmax3(fmax3(v[0], v[1], v[2]), v[3], v[4]), v[5], v[6]);
+            m = fmax3(fmax3(fmax3(m, v[7], v[8]), v[9], v[10]), v[11], v[12]);
+            m = fmax2(fmax3(m, v[13], v[14]), v[15]);
+            return __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;      // norm_apply and the uint16 scale are applied by load16
+        };
+        auto load16 = [&](float (&v)[16], int z) {
 #pragma unroll
-        for (int q = 0; q < AHEAD; ++q) rr.issue(q);   // AHEAD 4-row blocks ahead
+            for (int q = 0; q < 16; ++q) {
+                float x = load_row(min(z + q, rows - 1));
+                if constexpr (NORM) x = norm_apply(x, na, nb);
+                v[q] = x;
+            }
+        };
+        float va[16], vb[16];
+        int zv = rows;
+        load16(va, 0);
+        for (int z = 0; z < rows; z += 32) {       // two 16-row chunks per trip, the next one in flight while this one is looked at
+            load16(vb, z + 16);
+            if (valid16(va)) { zv = z; break; }
+            if (z + 16 >= rows) break;
+            load16(va, z + 32);
+            if (valid16(vb)) { zv = z + 16; break; }
+        }
+        S = max(zv - 18, 0) & ~7;
+    }
+    const int m0 = S > 0 ? S + 9 : 0;            // first x5 row this wave accounts for
+
+    if constexpr (WIDE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scan's loads
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) rr.issue((S >> 2) + q);   // AHEAD 4-row blocks ahead
         rr.template wait<0>();                   // from here on the counted waits below see a fixed pattern of younger operations
     } else {
 #pragma unroll
-        for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(q - ROFF, 0), rows - 1));
+        for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));
     }
 
     int ti = 0x7fffffff, bi = -1;                // first / last valid row of X5 in this lane's column
 
     const int nsteps = rows + G::LAT;
-    for (int i0 = 0; i0 < nsteps; i0 += 8) {
+    for (int i0 = S; i0 < nsteps; i0 += 8) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int i = i0 + p;
@@ -330,7 +370,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             const float d7 = fmax3(T7[p], T7[(p + 5) & 7] /* rows i-11 .. i-9 */, H7[(p + 4) & 7] /* row i-12 */);
             const float e = E4[(p + 7) & 7];                             // row m = i-9
             const float x5 = e < thr ? d7 : e;
-            const bool inrows = (unsigned)m < (unsigned)rows;
+            const bool inrows = m >= m0 && m < rows;
             if (inrows) {
                 // ---- H6 bookkeeping (LO :112-121): first / last row with x > 0.1 (their values are re-read
                 // from the rows stored below, in the epilogue)
@@ -347,12 +387,22 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
     // value; a column without valid pixels ends as 100 everywhere (:110, :125-127)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's own stores, before it reads two of them back
-    float tv = ob.ld_at(oc + 4u * (unsigned)(min(ti, rows - 1) * cols)), bv = ob.ld_at(oc + 4u * (unsigned)(max(bi, 0) * cols));
-    if (bi < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
-    if (!outlane) { ti = -1; bi = rows; }
-    const int tmax = wave_max_i(ti);
-    for (int r = 0; r <= tmax; ++r)
-        if (r <= ti) ob.st(oc, r, cols, tv);
+    const float bv = ob.ld_at(oc + 4u * (unsigned)(max(bi, 0) * cols));
+    if (tcol) {
+        // table mode (k_fp_s reads X6): the rows above a column's first valid row all equal that row, so they are not written
+        // at all -- the reader clamps its row index to tcol[column] instead (a third of X6 on velodyne-like frames stays out of
+        // HBM, both ways).  An empty column is 100 everywhere: its table entry points at the last row, which holds the 100.
+        if (bi < 0) { ti = rows - 1; bi = rows; ob.st(outlane ? oc : kDropOffset, rows - 1, cols, 100.0f); }
+        if (outlane) tcol[(size_t)f * cols + gx] = ti;
+        if (!outlane) bi = rows;
+    } else {
+        float tv = ob.ld_at(oc + 4u * (unsigned)(min(ti, rows - 1) * cols));
+        if (bi < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
+        if (!outlane) { ti = -1; bi = rows; }
+        const int tmax = wave_max_i(ti);
+        for (int r = 0; r <= tmax; ++r)
+            if (r <= ti) ob.st(oc, r, cols, tv);
+    }
     const int bmin = wave_min_i(bi);
     for (int r = bmin; r < rows; ++r)
         if (r >= bi) ob.st(oc, r, cols, bv);
@@ -606,6 +656,7 @@ struct PostPipe {
     static constexpr bool do_blur = BLUR && MODE >= 10;
     MedianColumn mc;         // the vertical half of the median (dcmt_median.h)
     float G1[8], MR[8];      // horizontal Gaussian / median rows, slot (image row) & 7
+    float last_out;          // the value this lane stored last (k_fp_s repeats output row 0 above a shifted origin)
     // per-lane constants
     FrameBuf of;             // output frame
     unsigned ob;             // byte offset of this lane's (clamped) column
@@ -622,6 +673,7 @@ struct PostPipe {
         rl = reflect101(gx, cols) - gx0;      // reflect-101 source lane for the Gaussian's out-of-image columns
         edge_strip = gx0 < 0 || gx0 + 63 >= cols;
         mc.init();
+        last_out = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { G1[q] = 0.f; MR[q] = 0.f; }
     }
@@ -665,6 +717,7 @@ struct PostPipe {
                 }
                 if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
                 of.st(outlane ? ob : kDropOffset, o, cols, val);     // every lane stores; halo lanes aim past the buffer (dropped)
+                last_out = val;
             };
             const float g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7];
             const float g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];
@@ -776,7 +829,7 @@ __device__ __forceinline__ void row_scans3(float a, float b, float& pa, float& s
 
 __global__ __launch_bounds__(256)
 void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo)
+              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tcol)
 {
     const int lane = threadIdx.x & 63;
     int f, sg;
@@ -793,6 +846,9 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     const float* sp = in + fo + gxc;
     float* op = out + fo + gxc;
     const int a_lo = ((lane - FillS::R) & 63) * 4, a_hi = ((lane + FillS::R) & 63) * 4;   // bpermute byte addresses
+    // tcol: `in` is an X6 whose rows above each column's first valid row were never written (k_pre_s, table mode): they
+    // equal that row, so the row index is clamped per lane
+    const int tl = tcol ? tcol[(size_t)f * cols + gxc] : 0;
 
     // rolling rows, slot = row & 15 (16-step unroll keeps every index static)
     float PF[16], XC[16], W2[16], W4[16], W8[16], W16[16];
@@ -801,7 +857,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     // step t handles the (row-clamped) input row v = t - 15 and emits output row o = t - 30
     constexpr int PFD = 8;
 #pragma unroll
-    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(q - FillS::R, 0), rows - 1) * cols];
+    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)max(min(max(q - FillS::R, 0), rows - 1), tl) * cols];
     float vprev = -FLT_MAX;
     int before = 0, after = 0;
     const int nsteps = rows + 2 * FillS::R;
@@ -810,7 +866,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
         for (int p = 0; p < 16; ++p) {
             const int t = t0 + p;
             const float x = PF[p];
-            PF[(p + PFD) & 15] = sp[(size_t)min(max(t + PFD - FillS::R, 0), rows - 1) * cols];
+            PF[(p + PFD) & 15] = sp[(size_t)max(min(max(t + PFD - FillS::R, 0), rows - 1), tl) * cols];
             XC[p] = x;
             // vertical: windows ending at row t of 2, 4, 8, 16, 31 rows
             const float w2 = fmax2(x, vprev);
@@ -877,7 +933,7 @@ struct FpS {
 template <bool BLUR>
 __global__ __launch_bounds__(256)
 void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
-            int rows, int cols, int strips, int batch, int xcd_map, float max_depth, float thr)
+            int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tcol)
 {
     // per wave, three 15-step delay lines: centre values, A's 16-row maxima (64 lanes each), B's 16-row
     // maxima (only its 30 halo lanes: packed to 32) -- 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
@@ -887,17 +943,37 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     int f, strip;
     if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;
     int* cnt = frame_counters(counters, f);
-    const size_t fo = (size_t)f * rows * cols;
+    const size_t fo = (size_t)f * rows_all * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
     const int gxa = gx0 + lane;
     // B: lanes 0..14 = the 15 columns right of the strip (ascending); lanes 49..63 = the 15 columns left of it
     // in DESCENDING order (lane 49 = gx0-1 ... lane 63 = gx0-15; lane 48 duplicates gx0-1), so that the
     // suffix the left side needs is a PREFIX over lanes too and one row scan serves both halos
     const int gxb = lane <= 14 ? gx0 + 64 + lane : (lane >= 49 ? gx0 + 48 - lane : (lane == 48 ? gx0 - 1 : gxa));
+    const int gxac = min(max(gxa, 0), cols - 1), gxbc = min(max(gxb, 0), cols - 1);   // clamped: replicate == constant border for a max filter
+    // ---- the top extension zone.  k_pre_s (table mode) leaves the rows above each column's first valid row ti unwritten:
+    // they all equal row ti, so a row index is clamped per lane to ti.  With T = the smallest ti of the 94 columns this wave
+    // reads, rows 0 .. T of X6 are constant down every one of those columns and hole-free, hence so are X7 (rows <= T),
+    // the median (rows <= T - 2) and the output (rows <= T - 4, whichever border rule the top rows use).  The wave therefore
+    // treats row V = T - 8 as the top of its frame: the clamped row loads reproduce the real rows above V (they equal row V),
+    // the median's replicated and the Gaussian's reflected rows above V are rows of the constant zone like the real ones,
+    // and the first output row (V) is stored to rows 0 .. V-1 as well -- on velodyne-like frames (upper third empty) that is
+    // a quarter of the row steps of this kernel.
+    int tia = 0, tib = 0, V = 0;
+    if (tcol) {
+        tia = tcol[(size_t)f * cols + gxac]; tib = tcol[(size_t)f * cols + gxbc];
+        V = __builtin_amdgcn_readfirstlane(max(wave_min_i(min(tia, tib)) - 8, 0));   // wave-uniform: keep the row arithmetic scalar
+    }
+    const int rows = rows_all - V;                                   // rows of the frame as this wave sees it (>= 9)
     FrameBuf sf;
-    sf.init(x6 + fo, (size_t)rows * cols);
-    const unsigned sba = 4u * (unsigned)min(max(gxa, 0), cols - 1);   // clamped: replicate == constant border for a max filter
-    const unsigned sbb = 4u * (unsigned)min(max(gxb, 0), cols - 1);
+    sf.init(x6 + fo, (size_t)rows_all * cols);
+    const unsigned rowb = 4u * (unsigned)cols;
+    const unsigned sba = 4u * (unsigned)gxac + (unsigned)V * rowb;   // byte offset of (row V, this lane's column)
+    const unsigned sbb = 4u * (unsigned)gxbc + (unsigned)V * rowb;
+    const unsigned fla = 4u * (unsigned)gxac + (unsigned)max(tia, V) * rowb;   // no row above ti is ever read
+    const unsigned flb = 4u * (unsigned)gxbc + (unsigned)max(tib, V) * rowb;
+    auto ld_a = [&](int row) -> float { return sf.ld_at(max(sba + (unsigned)row * rowb, fla)); };   // row relative to V, already clamped to [0, rows)
+    auto ld_b = [&](int row) -> float { return sf.ld_at(max(sbb + (unsigned)row * rowb, flb)); };
     const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
     const unsigned long long own_mask = __ballot(own);          // wave-uniform: the hole counts stay on the scalar unit
     const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;
@@ -909,7 +985,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     const int lb = lane <= 14 ? lane : (lane >= 48 ? lane - 32 : 15);   // B's live lanes 0..14, 48..63 -> words 0..14, 16..31; the dead lanes share word 15
 
     PostPipe<11, BLUR> pipe;
-    pipe.init(dst + fo, rows, cols, gx0, lane, max_depth, thr);
+    pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
 
     constexpr float NEG = -FLT_MAX;
     float PFA[16], PFB[16], W2A[16], W4A[16], W8A[16], W2B[16], W4B[16], W8B[16], DL[8];
@@ -926,7 +1002,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
         const int row = min(max(q - 15, 0), rows - 1);
-        PFA[q] = sf.ld(sba, row, cols); PFB[q] = sf.ld(sbb, row, cols);
+        PFA[q] = ld_a(row); PFB[q] = ld_b(row);
     }
     float vpa = NEG, vpb = NEG, x7_prev = 0.f;
     int before = 0, after = 0;
@@ -943,7 +1019,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         const float xa = PFA[p], xb = PFB[p];
         {
             const int row = min(max(t + PFD - 15, 0), rows - 1);
-            PFA[(p + PFD) & 15] = sf.ld(sba, row, cols); PFB[(p + PFD) & 15] = sf.ld(sbb, row, cols);
+            PFA[(p + PFD) & 15] = ld_a(row); PFB[(p + PFD) & 15] = ld_b(row);
         }
         // finish row t - 1 - 30 from what step t - 1 left pending
         const int o = t - 31;
@@ -1014,6 +1090,15 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             const int t = t0 + p, u = t - FpS::LAG;
             DL[p & 7] = fill_step(P_, t);
             pipe.template step<(p & 7)>(DL[(p + 5) & 7], u);
+            if constexpr (p == 6) {
+                // u == 6: output row 0 of the shifted frame (image row V) has just been stored; the V rows above it are equal
+                if (t0 == FpS::LAG && V > 0) {
+                    FrameBuf top;
+                    top.init(dst + fo, (size_t)V * cols);
+                    const unsigned tb = pipe.outlane ? pipe.ob : kDropOffset;
+                    for (int r = 0; r < V; ++r) top.st(tb, r, cols, pipe.last_out);
+                }
+            }
         });
     }
     if (lane == 0) {
