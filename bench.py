@@ -4,17 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A step = one pass of the hot path (dcmt_complete_f32_dev, all kernels of the cascade) over
-one device-resident batch of `--batch` synthetic 352x1216 sparse-depth frames per GPU.
-Frames are independent, so ranks shard the frames with NO collective on the data path
-(torch.distributed is used for the barriers and the max-over-ranks of the elapsed time
-only); scaling is weak: every rank processes its own `--batch` frames per step.
+A step = one pass of the hot path (dcmt_complete_f32_dev, all kernels of the cascade) over the device-resident frames
+this rank owns.  Default = BASELINE configs[4] as written: `--total-frames 1024` synthetic 352x1216 sparse-depth frames
+sharded per frame over the N ranks (depth_completion_mt_amd.sharding.shard_range: 1024 / 512 / 256 / 128 per GPU at
+N = 1 / 2 / 4 / 8), i.e. STRONG scaling; at N = 1 that is the 1024-frame batch the metric is quoted on.  `--weak` gives
+every rank its own `--batch` frames instead (and says so in "scaling").  Frames are independent: NO collective on the
+data path; torch.distributed carries the barriers and the max-over-ranks of the elapsed time only.
 
-Prints ONE JSON line (rank 0).  value = frames/s over all ranks.  roofline.achieved =
-algorithmic bytes (8 B/px: sparse f32 in + dense f32 out, intermediates count zero) per
-step / mean GPU time per step measured with HIP events on the launch stream.
-cpu_baseline = the CPU oracle (a port: OpenCV is not installed, the reference cannot be
-built) on this box's host cores, frame-parallel, bounded sample.
+Prints ONE JSON line (rank 0).  value = frames/s over all ranks.
+  roofline      whole cascade of one step on one GPU: algorithmic bytes (8 B/px: sparse f32 in + dense f32 out, intermediates
+                count zero) / mean GPU time per step, HIP events on the launch stream; .per_kernel = the library's own events
+                around k_pre_s / k_fp_s (dcmt_set_kernel_timing) in an extra untimed pass; .valu = the instruction-issue
+                side (what actually binds both kernels), from the SQ counters of profiles/valu_latest.json; .traffic from the
+                PMC passes of profiles/traffic_latest.json (both written by tools/collect_profiles.sh on the builder's box).
+  configs       (rank 0, N = 1) the other BASELINE configs, each with its own roofline: [1] batch = 1 streamed,
+                [2] DC_lidar_camera 352x1216 + labels, [3] DC_stereo_lidar 375x1242 + labels; plus the per-GPU workload of
+                configs[4] at 8 GPUs (128 frames per step) on this one GPU.
+  cpu_baseline  the CPU oracle (a port: OpenCV is not installed, the reference cannot be built) on this box's host cores,
+                frame-parallel, bounded sample.
 """
 from __future__ import annotations
 
@@ -32,6 +39,8 @@ ROWS, COLS = 352, 1216
 BYTES_PER_FRAME = ROWS * COLS * 8           # read 1,712,128 + write 1,712,128
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0               # same guide: measured float4-copy ceiling
+N_SIMD, CLOCK_HZ = 1024, 2.4e9              # 256 CUs x 4 SIMDs, max clock
+METRIC = "depth frames/sec at 1216x352 (KITTI); achieved HBM GB/s vs peak"
 
 
 def cpu_baseline(n_threads: int, cpu_work_s: float = 16.0):
@@ -64,39 +73,214 @@ def cpu_baseline(n_threads: int, cpu_work_s: float = 16.0):
             "single_thread_frames_per_s": 1.0 / t1}
 
 
-def dry_run(args, rank, world):
-    """The rank protocol of the real run -- barrier, K timed steps, barrier, max over ranks, one JSON line from
-    rank 0 -- over gloo with the GPU step replaced by a sleep.  Exercised by tests/test_sharding.py on CPU."""
-    import torch
-    import torch.distributed as dist
+def frames_of_rank(args, rank: int, world: int) -> int:
+    """Frames this rank owns per step: a shard of --total-frames (strong scaling, the default), or --batch (--weak)."""
     from depth_completion_mt_amd import sharding
+    if args.weak:
+        return args.batch
+    b, e = sharding.shard_range(args.total_frames, rank, world)
+    return e - b
+
+
+def all_reduce_max(dist, values, device=None):
+    """MAX over ranks of a list of floats (identity without a process group)."""
+    if dist is None:
+        return list(values)
+    import torch
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def dry_run(args, rank, world):
+    """The rank protocol of the real run -- shard, barrier, K timed steps, barrier, max over ranks (status first), one JSON
+    line from rank 0 -- over gloo with the GPU step replaced by a sleep.  Exercised by tests/test_sharding.py on CPU."""
+    dist = None
     if world > 1:
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    B = args.batch
-    b, e = sharding.shard_range(B * world, rank, world)            # weak scaling: every rank owns B frames
-    assert e - b == B
+    B = frames_of_rank(args, rank, world)
+    total = args.batch * world if args.weak else args.total_frames
     for _ in range(args.warmup):
         time.sleep(0.001)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.002 * (rank + 1))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    if rank == 0:
-        print(json.dumps({"metric": "depth frames/sec at 1216x352 (KITTI); achieved HBM GB/s vs peak", "value": B * world * args.steps / elapsed,
-                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "dry run (no GPU work)", "config": {"workload": "dry run", "frames_per_gpu_per_step": B}}))
-    if world > 1:
+    failed = 1.0 if (args.dry_run_fail_rank is not None and rank == args.dry_run_fail_rank) else 0.0
+    failed, elapsed = all_reduce_max(dist, [failed, elapsed])          # every rank learns of a failure BEFORE anyone leaves
+    if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("a rank reported a failed step: no result")
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": total * args.steps / elapsed,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry run (no GPU work)",
+                          "config": {"workload": "dry run", "total_frames_per_step": total, "frames_per_gpu_per_step": B}}))
+
+
+def timed(torch, fn, n, stream):
+    """Mean milliseconds of n calls of fn, HIP events on `stream` (after 2 untimed calls)."""
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(n):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def hbm_roofline(bytes_per_step: float, ms: float) -> dict:
+    a = bytes_per_step / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+            "frac_of_measured_copy_ceiling": a / HBM_COPY_CEILING_GBS, "gpu_ms_per_step": ms, "algorithmic_bytes_per_step": bytes_per_step}
+
+
+def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
+    """BASELINE configs [1], [2], [3] and the per-GPU share of [4] at 8 GPUs, on this one GPU, each with its own roofline
+    (reference call sites: DC_lidar_only/main.cpp:93, DC_lidar_camera/main_lc.cpp:220, DC_stereo_lidar/main_sl.cpp:540)."""
+    from depth_completion_mt_amd import Context, make_params, synth
+    out = {}
+    B = d_src.shape[0]
+    # [1] DC_lidar_only, batch = 1 streamed: one frame per call, back to back on one stream (device-resident frames; the
+    # PCIe-inclusive forms are in --batch1).  Latency-bound by construction: a frame's ideal HBM time is 0.43 us.
+    c1 = Context(local_rank, ROWS, COLS, 1)
+    k = [0]
+    def one():
+        c1.complete_dev(d_src[k[0] % B], d_dst[k[0] % B], params, stream=stream.cuda_stream)
+        k[0] += 1
+    ms = timed(torch, one, 200, stream)
+    out["1"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, batch=1 streamed (one dcmt_complete_f32_dev call per frame, one stream)",
+                "value": 1e3 / ms, "unit": "frames/s", "us_per_frame": ms * 1e3, "roofline": hbm_roofline(BYTES_PER_FRAME, ms)}
+    c1.close()
+    # [4] at 8 GPUs = 128 frames per GPU per step: that per-GPU workload on this GPU
+    b128 = min(128, B)
+    c4 = Context(local_rank, ROWS, COLS, b128)
+    ms = timed(torch, lambda: c4.complete_dev(d_src[:b128], d_dst[:b128], params, stream=stream.cuda_stream), steps, stream)
+    out["4_per_gpu_share"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {b128} frames per step (the per-GPU shard of 1024 frames on 8 GPUs)",
+                              "value": b128 * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(b128 * BYTES_PER_FRAME, ms)}
+    c4.close()
+    # [2] DC_lidar_camera 352x1216 + int32 label plane (~1200 superpixels, main_lc.cpp:188-197); [3] DC_stereo_lidar 375x1242 (~100, main_sl.cpp:443)
+    for key, rows, cols, nt, name in (("2", 352, 1216, 1200, "DC_lidar_camera"), ("3", 375, 1242, 100, "DC_stereo_lidar")):
+        Bl = 256
+        lab, nl = synth.synth_labels(rows, cols, nt, 0)
+        d = torch.from_numpy(synth.synth_batch(8, rows, cols, 0)).cuda().repeat(Bl // 8, 1, 1).contiguous()
+        dl = torch.from_numpy(lab).cuda()[None].repeat(Bl, 1, 1).contiguous()
+        o = torch.empty_like(d)
+        c = Context(local_rank, rows, cols, Bl)
+        ms = timed(torch, lambda: c.complete_dev(d, o, params, d_labels=dl, n_labels=nl, stream=stream.cuda_stream), max(steps // 2, 5), stream)
+        c.set_kernel_timing(True)
+        c.complete_dev(d, o, params, d_labels=dl, n_labels=nl, stream=stream.cuda_stream)
+        kt = c.last_kernel_times()
+        iters, st = c.last_fill_iters(Bl)
+        out[key] = {"workload": f"{name} interpolate_with_superpixels, {cols}x{rows} f32 + int32 labels ({nl} labels), device-resident batch of {Bl}",
+                    "value": Bl * 1e3 / ms, "unit": "frames/s", "converged": st == 0,
+                    "roofline": dict(hbm_roofline(Bl * rows * cols * 12, ms), per_kernel_ms={"label_stage": kt["front"], "k_pre_s": kt["k_pre_s"], "k_fp_s": kt["k_fp_s"]})}
+        c.close()
+        del d, dl, o
+    return out
+
+
+def batch1_extras(torch, np, L, local_rank, host, uniq, d_src, d_dst, params):
+    """--batch1: BASELINE configs[1] in its PCIe-inclusive forms (never the reported value)."""
+    from depth_completion_mt_amd import Context, make_params
+    import ctypes
+    extra = {}
+    B = d_src.shape[0]
+    n1 = 400
+    for nstreams in (1, 4):
+        ctxs = [Context(local_rank, ROWS, COLS, 1) for _ in range(nstreams)]
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        def run(n):
+            for i in range(n):
+                k = i % nstreams
+                ctxs[k].complete_dev(d_src[i % B], d_dst[i % B], params, stream=streams[k].cuda_stream)
+        run(4 * nstreams)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(n1)
+        torch.cuda.synchronize()
+        extra["batch1_streamed_frames_per_s" if nstreams == 1 else f"batch1_streamed_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
+        for c in ctxs:
+            c.close()
+    # host-pinned input and output, frames arriving one at a time: per frame an H2D copy, the cascade on that one frame, a D2H
+    # copy, all stream-ordered; four streams keep the PCIe copies of one frame under the kernels of another
+    for nstreams in (1, 4):
+        ctxs = [Context(local_rank, ROWS, COLS, 1) for _ in range(nstreams)]
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        h_in = [torch.from_numpy(host[i % uniq]).pin_memory() for i in range(nstreams)]
+        h_out = [torch.empty((ROWS, COLS), dtype=torch.float32).pin_memory() for _ in range(nstreams)]
+        dv_in = [torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda") for _ in range(nstreams)]
+        dv_out = [torch.empty_like(dv_in[0]) for _ in range(nstreams)]
+        def run_pinned(n):
+            for i in range(n):
+                k = i % nstreams
+                with torch.cuda.stream(streams[k]):
+                    dv_in[k].copy_(h_in[k], non_blocking=True)
+                    ctxs[k].complete_dev(dv_in[k], dv_out[k], params, stream=streams[k].cuda_stream)
+                    h_out[k].copy_(dv_out[k], non_blocking=True)
+        run_pinned(4 * nstreams)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_pinned(n1)
+        torch.cuda.synchronize()
+        extra["batch1_host_pinned_frames_per_s" if nstreams == 1 else f"batch1_host_pinned_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
+        for c in ctxs:
+            c.close()
+    # the drop-in itself: dcmt_complete_f32 on pageable host arrays, one synchronous call per frame (what the cv::Mat shim does)
+    hctx = Context(local_rank, ROWS, COLS, 1)
+    hp = make_params()
+    h_dst = np.empty((ROWS, COLS), np.float32)
+    def host_call(i):
+        src = host[i % uniq]
+        st = L.lib().dcmt_complete_f32(hctx._h, src.ctypes.data, src.strides[0], 0, h_dst.ctypes.data, h_dst.strides[0], 0,
+                                       ROWS, COLS, 1, ctypes.byref(hp))
+        assert st == L.OK
+    for i in range(8):
+        host_call(i)
+    t1 = time.perf_counter()
+    for i in range(n1):
+        host_call(i)
+    extra["batch1_host_api_frames_per_s"] = n1 / (time.perf_counter() - t1)
+    hctx.close()
+    # the same single-frame call captured once into a HIP graph and replayed
+    gctx = Context(local_rank, ROWS, COLS, 1)
+    gs = torch.cuda.Stream()
+    gsrc, gdst = d_src[0].clone(), torch.empty_like(d_src[0])
+    with torch.cuda.stream(gs):
+        gctx.complete_dev(gsrc, gdst, params, stream=gs.cuda_stream)          # warm up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=gs):
+        gctx.complete_dev(gsrc, gdst, params, stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(8):
+        graph.replay()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n1):
+        graph.replay()
+    torch.cuda.synchronize()
+    extra["batch1_graph_replay_frames_per_s"] = n1 / (time.perf_counter() - t1)
+    gctx.close()
+    return extra
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def main():
@@ -104,26 +288,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames per GPU (tiled to --batch)")
+    ap.add_argument("--total-frames", type=int, default=1024, help="frames per step over ALL ranks, sharded per frame (BASELINE configs[4]: 1024)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every rank owns --batch frames per step")
+    ap.add_argument("--batch", type=int, default=1024, help="--weak: frames per GPU per step")
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames per GPU (tiled to the rank's frame count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch1", action="store_true", help="also time batch=1 streamed launches (configs[1])")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-results for BASELINE configs [1] [2] [3]")
+    ap.add_argument("--batch1", action="store_true", help="also time the PCIe-inclusive forms of configs[1]")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the multi-rank protocol (gloo, no GPU work, value is meaningless): tests only")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=None, help="tests only: that rank reports a failed step")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    from depth_completion_mt_amd import Context, make_params, synth
-    from depth_completion_mt_amd import _lib as L
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not args.weak and args.total_frames < world:
+        raise SystemExit("--total-frames must give every rank at least one frame")
     if args.dry_run:
         return dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
+    from depth_completion_mt_amd import Context, make_params, synth
+    from depth_completion_mt_amd import _lib as L
     if not torch.cuda.is_available() or L.lib().dcmt_device_count() < 1:
         raise SystemExit("bench.py needs a gfx950 GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -133,7 +323,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    B = args.batch
+    B = frames_of_rank(args, rank, world)                # frames this rank owns per step
+    total = args.batch * world if args.weak else args.total_frames
     uniq = min(args.unique, B)
     host = synth.synth_batch(uniq, ROWS, COLS, seed0=rank * 100003)
     d_uniq = torch.from_numpy(host).cuda()
@@ -168,149 +359,72 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream
 
-    # every frame must have converged inside the timed configuration (no skipped work)
+    # every frame must have converged inside the timed configuration (no skipped work).  The status goes through the same
+    # all-reduce as the times, so that a failing rank cannot leave the others waiting in a collective.
     iters, st = ctx.last_fill_iters(B)
-    if st != L.OK:
+    failed, elapsed, gpu_ms_per_step = all_reduce_max(dist, [0.0 if st == L.OK else 1.0, elapsed, gpu_ms_per_step], device="cuda")
+    if failed:
+        if dist is not None:
+            dist.destroy_process_group()
         raise SystemExit("a frame needed more hole-closure applications than were enqueued: result invalid")
 
-    if dist is not None:
-        t = torch.tensor([elapsed, gpu_ms_per_step], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms_per_step = float(t[0]), float(t[1])
-
-    extra = {}
     if rank == 0:
-        # per-kernel split, live: the same batch with stop_after = column extension runs k_pre_s alone (same kernel, same
-        # reads and writes; its output goes to d_dst instead of the scratch plane); k_fp_s = the step minus that.
-        # Outside the timed region; cross-checks the rocprofv3 per-kernel averages in profiles/.
-        pre_params = make_params(stop_after=L.STAGE_EXTEND)
-        for _ in range(2):
-            ctx.complete_dev(d_src, d_dst, pre_params, stream=stream.cuda_stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(args.steps):
-            ctx.complete_dev(d_src, d_dst, pre_params, stream=stream.cuda_stream)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        pre_ms = e0.elapsed_time(e1) / args.steps
-        extra["per_kernel_ms"] = {"k_pre_s": pre_ms, "k_fp_s_by_difference": gpu_ms_per_step - pre_ms}
-    if args.batch1 and rank == 0:
-        # BASELINE configs[1]: frames arrive one at a time (batch = 1 per call).  One context + stream per
-        # in-flight frame; independent frames overlap on the GPU, each call is still a whole cascade on one frame.
-        n1 = 400
-        for nstreams in (1, 4):
-            ctxs = [Context(local_rank, ROWS, COLS, 1) for _ in range(nstreams)]
-            streams = [torch.cuda.Stream() for _ in range(nstreams)]
-            def run(n):
-                for i in range(n):
-                    k = i % nstreams
-                    ctxs[k].complete_dev(d_src[i % B], d_dst[i % B], params, stream=streams[k].cuda_stream)
-            run(4 * nstreams)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run(n1)
-            torch.cuda.synchronize()
-            extra["batch1_streamed_frames_per_s" if nstreams == 1 else f"batch1_streamed_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
-            for c in ctxs:
-                c.close()
-        # BASELINE configs[1] as SURVEY.md section 8d words it: host-pinned input and output, frames arriving one at a time --
-        # per frame an H2D copy, the cascade on that one frame, a D2H copy, all stream-ordered; four streams keep the PCIe
-        # copies of one frame under the kernels of another
-        for nstreams in (1, 4):
-            ctxs = [Context(local_rank, ROWS, COLS, 1) for _ in range(nstreams)]
-            streams = [torch.cuda.Stream() for _ in range(nstreams)]
-            h_in = [torch.from_numpy(host[i % uniq]).pin_memory() for i in range(nstreams)]
-            h_out = [torch.empty((ROWS, COLS), dtype=torch.float32).pin_memory() for _ in range(nstreams)]
-            dv_in = [torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda") for _ in range(nstreams)]
-            dv_out = [torch.empty_like(dv_in[0]) for _ in range(nstreams)]
-            def run_pinned(n):
-                for i in range(n):
-                    k = i % nstreams
-                    with torch.cuda.stream(streams[k]):
-                        dv_in[k].copy_(h_in[k], non_blocking=True)
-                        ctxs[k].complete_dev(dv_in[k], dv_out[k], params, stream=streams[k].cuda_stream)
-                        h_out[k].copy_(dv_out[k], non_blocking=True)
-            run_pinned(4 * nstreams)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run_pinned(n1)
-            torch.cuda.synchronize()
-            extra["batch1_host_pinned_frames_per_s" if nstreams == 1 else f"batch1_host_pinned_{nstreams}streams_frames_per_s"] = n1 / (time.perf_counter() - t1)
-            for c in ctxs:
-                c.close()
-        # and the drop-in itself: dcmt_complete_f32 on pageable host arrays, one synchronous call per frame -- what the
-        # cv::Mat shim does for the reference's own mains
-        import ctypes
-        hctx = Context(local_rank, ROWS, COLS, 1)
-        hp = make_params()
-        h_dst = np.empty((ROWS, COLS), np.float32)                 # the C entry point itself, on preallocated arrays
-        def host_call(i):
-            src = host[i % uniq]
-            st = L.lib().dcmt_complete_f32(hctx._h, src.ctypes.data, src.strides[0], 0, h_dst.ctypes.data, h_dst.strides[0], 0,
-                                           ROWS, COLS, 1, ctypes.byref(hp))
-            assert st == L.OK
-        for i in range(8):
-            host_call(i)
-        t1 = time.perf_counter()
-        for i in range(n1):
-            host_call(i)
-        extra["batch1_host_api_frames_per_s"] = n1 / (time.perf_counter() - t1)
-        hctx.close()
-        # the same single-frame call captured once into a HIP graph and replayed: the entry point never synchronises or
-        # allocates, so its memsets and kernel launches are capturable as they are; the replay removes the per-launch host cost
-        gctx = Context(local_rank, ROWS, COLS, 1)
-        gs = torch.cuda.Stream()
-        gsrc, gdst = d_src[0].clone(), torch.empty_like(d_src[0])
-        with torch.cuda.stream(gs):
-            gctx.complete_dev(gsrc, gdst, params, stream=gs.cuda_stream)          # warm up outside the capture
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=gs):
-            gctx.complete_dev(gsrc, gdst, params, stream=torch.cuda.current_stream().cuda_stream)
-        for _ in range(8):
-            graph.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            graph.replay()
-        torch.cuda.synchronize()
-        extra["batch1_graph_replay_frames_per_s"] = n1 / (time.perf_counter() - t1)
-        gctx.close()
-
-    if rank == 0:
-        frames_total = B * world * args.steps
-        value = frames_total / elapsed
-        achieved = B * BYTES_PER_FRAME / (gpu_ms_per_step * 1e-3) / 1e9      # GB/s per GPU, whole chain
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")       # written by tools/pmc_traffic.py
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
-            except Exception:
-                traffic = None
+        # live per-kernel split: one more (untimed) step with the library's own events around its kernel groups
+        ctx.set_kernel_timing(True)
+        kt = [0.0, 0.0, 0.0, 0.0]
+        nk = 5
+        for _ in range(nk):
+            step()
+            t = ctx.last_kernel_times()
+            kt = [a + b / nk for a, b in zip(kt, (t["front"], t["k_pre_s"], t["k_fp_s"], t["behind"]))]
+        ctx.set_kernel_timing(False)
+        roof = hbm_roofline(B * BYTES_PER_FRAME, gpu_ms_per_step)
+        roof["kernel"] = ("whole cascade per step = k_pre_s + k_fp_s (+ 3 redo launches that return at once), HIP events around the K timed steps "
+                          "on the launch stream; per_kernel: the library's own events (dcmt_set_kernel_timing) in 5 extra steps; rocprofv3 averages in profiles/")
+        roof["per_kernel"] = {"k_pre_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
+                              "k_fp_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="reads X6, writes the dense frame"),
+                              "redo_launches_ms": kt[3]}
+        tr = load_profile_json("traffic_latest.json")
+        roof["traffic"] = tr.get("hbm_bytes_per_step") if tr else None
+        if tr and B == 1024:
+            roof["traffic_over_algorithmic"] = tr["hbm_bytes_per_step"] / (B * BYTES_PER_FRAME)
+        roof["traffic_source"] = "profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the 1024-frame step on the builder's box (tools/collect_profiles.sh), not measured in this run"
+        va = load_profile_json("valu_latest.json")
+        if va and B == 1024:
+            # instruction-issue side: what binds both kernels.  SQ_ACTIVE_INST_VALU counts quad-cycles (x4 = SIMD cycles issuing VALU)
+            issue_ms = {k: v["active_inst_valu"] * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3 for k, v in va["kernels"].items()}
+            tot_issue = sum(issue_ms.values())
+            roof["valu"] = {"insts_per_step": sum(v["insts_valu"] for v in va["kernels"].values()),
+                            "insts_per_step_by_kernel": {k: v["insts_valu"] for k, v in va["kernels"].items()},
+                            "cycles_per_inst": sum(v["active_inst_valu"] for v in va["kernels"].values()) * 4.0 / sum(v["insts_valu"] for v in va["kernels"].values()),
+                            "issue_ms_per_step": tot_issue, "issue_ms_by_kernel": issue_ms,
+                            "frac_of_issue": tot_issue / gpu_ms_per_step,
+                            "peak": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz; min/max/med3/cmp/cndmask/DPP issue at ~4.4 cycles per wave64 instruction (tools/issue_probe.hip)",
+                            "source": "profiles/valu_latest.json: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU pass of this step on the builder's box"}
+            roof["limiter"] = "valu-issue" if roof["valu"]["frac_of_issue"] > 0.6 else "mixed"
         line = {
-            "metric": "depth frames/sec at 1216x352 (KITTI); achieved HBM GB/s vs peak",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC, "value": total * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic KITTI-like sparse depth (depth_completion_mt_amd/synth.py), {uniq} distinct frames per GPU tiled to {B}",
-            "config": {"workload": f"DC_lidar_only img_completion, {COLS}x{ROWS} f32, device-resident batch of {B} frames per GPU per step "
-                                   f"(BASELINE configs[4] sharding; configs[1] batch=1 is latency-bound, see --batch1)",
-                       "frames_per_gpu_per_step": B, "rows": ROWS, "cols": COLS, "k0": "as_compiled", "blur": "gaussian",
+            "config": {"workload": (f"DC_lidar_only img_completion, {COLS}x{ROWS} f32, {total} device-resident frames per step "
+                                    + (f"= {args.batch} per GPU (weak scaling)" if args.weak else
+                                       f"sharded per frame over {world} GPU(s) = {B} per GPU (BASELINE configs[4]; strong scaling)")),
+                       "total_frames_per_step": total, "frames_per_gpu_per_step": B, "rows": ROWS, "cols": COLS, "k0": "as_compiled", "blur": "gaussian",
                        "sharding": "per-frame, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                         "gpu_ms_per_step": gpu_ms_per_step, "algorithmic_bytes_per_step": B * BYTES_PER_FRAME,
-                         "kernel": "whole cascade per step = k_pre_s + k_fp_s (+ 3 skipped redo launches), HIP events around each step on the launch stream; live per-kernel split in per_kernel_ms, rocprofv3 averages in profiles/"},
+            "roofline": roof,
             "fill_iters_max": max(iters),
         }
-        line.update(extra)
+        if world == 1 and not args.no_configs:
+            line["configs"] = other_configs(torch, local_rank, d_src, d_dst, params, stream, args.steps)
+        if args.batch1:
+            line.update(batch1_extras(torch, np, L, local_rank, host, uniq, d_src, d_dst, params))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))   # the box's CPU share for one GPU is 16
         print(json.dumps(line))
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

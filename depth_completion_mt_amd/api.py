@@ -232,6 +232,20 @@ class Context:
             raise DcmtError(st, "dcmt_last_fill_iters")
         return list(out), st
 
+    def set_kernel_timing(self, on: bool = True):
+        """Measurement aid: HIP events around the kernel groups of the streaming path of every following *_dev call."""
+        st = L.lib().dcmt_set_kernel_timing(self._h, int(bool(on)))
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_set_kernel_timing")
+
+    def last_kernel_times(self) -> dict:
+        """Milliseconds of the last *_dev call's kernel groups (synchronises with its stream)."""
+        ms = (ctypes.c_float * 4)()
+        st = L.lib().dcmt_last_kernel_times(self._h, ms)
+        if st != L.OK:
+            raise DcmtError(st, "dcmt_last_kernel_times")
+        return {"front": ms[0], "k_pre_s": ms[1], "k_fp_s": ms[2], "behind": ms[3]}
+
     def last_holes_after_extend(self, n: int):
         out = (ctypes.c_int * n)()
         st = L.lib().dcmt_last_holes_after_extend(self._h, out, n)

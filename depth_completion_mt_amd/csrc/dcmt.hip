@@ -44,6 +44,9 @@ struct dcmt_ctx {
     int last_apps_launched = 0;       // loop applications (app >= 1) enqueued
     int last_has_loop = 0;            // the call went at least through H8
     int last_hip_error = 0;
+    int timing = 0;                   // dcmt_set_kernel_timing: events around the kernel groups of the streaming path
+    hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int tev_valid = 0;                // the last call recorded all five
     int poison = 0;                   // env DCMT_POISON=1: fill the staging output with NaN before every host call
     int chunk = 0;                    // frames per chunk of the fused path (0 = whole batch); env DCMT_CHUNK
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
@@ -202,6 +205,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     ctx->last_apps_launched = 0;
     ctx->last_has_loop = 0;
     DCMT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(int) * (size_t)batch * kCntStride, st));
+    auto stamp = [&](int i) { if (ctx->timing && ctx->tev[i]) (void)hipEventRecord(ctx->tev[i], st); };
+    stamp(1);
     const size_t fe = (size_t)rows * cols;
     const int chunk = (ctx->chunk > 0 && !sync_loop) ? ctx->chunk : batch;   // the host-synchronised loop works on the whole batch
     const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
@@ -236,6 +241,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
 #undef DCMT_PRE
             DCMT_HIP(ctx, hipGetLastError());
+            stamp(2);
             if (stop == DCMT_STAGE_EXTEND) continue;
         }
         const int fstrips = (cols + FillS::VW - 1) / FillS::VW;
@@ -249,6 +255,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc);
             else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc);
             DCMT_HIP(ctx, hipGetLastError());
+            stamp(3);
             ctx->last_has_loop = 1;
             const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);
             if (n_redo > 0) {
@@ -272,6 +279,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 else    hipLaunchKernelGGL((k_post_s<11, false>), pg, b256, 0, st, pp0, pp1, dst, cnt, apps, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, 1);
                 DCMT_HIP(ctx, hipGetLastError());
             }
+            stamp(4);
+            ctx->tev_valid = ctx->timing && chunk == batch;
             continue;
         }
         hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
@@ -323,6 +332,8 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     const uint32_t kb = k0_bits(p->k0);
     const int stop = p->stop_after;
     const int blur = force_gaussian ? (int)DCMT_BLUR_GAUSSIAN : p->blur;
+    ctx->tev_valid = 0;
+    if (ctx->timing && ctx->tev[0]) (void)hipEventRecord(ctx->tev[0], st);
     const float* coef = nullptr;
     if (p->flags & DCMT_FLAG_NORMALIZE) {
         // N1: one read-only pass for the per-frame extrema, then (a, b) per frame; the first kernel of whichever
@@ -623,6 +634,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     (void)hipFree(ctx->slic_cells); (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]);
     (void)hipFree(ctx->slic_sums);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (auto e : ctx->tev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -897,5 +909,26 @@ int dcmt_last_holes_after_extend(dcmt_ctx* ctx, int* out, int n)
 }
 
 int dcmt_last_hip_error(const dcmt_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+int dcmt_set_kernel_timing(dcmt_ctx* ctx, int on)
+{
+    DCMT_ON_DEVICE(ctx);
+    if (!ctx) return DCMT_E_INVALID;
+    if (on)
+        for (auto& e : ctx->tev)
+            if (!e) DCMT_HIP(ctx, hipEventCreate(&e));
+    ctx->timing = on != 0;
+    ctx->tev_valid = 0;
+    return DCMT_OK;
+}
+
+int dcmt_last_kernel_times(dcmt_ctx* ctx, float ms[DCMT_N_KERNEL_TIMES])
+{
+    DCMT_ON_DEVICE(ctx);
+    if (!ctx || !ms || !ctx->tev_valid) return DCMT_E_INVALID;
+    DCMT_HIP(ctx, hipEventSynchronize(ctx->tev[4]));
+    for (int i = 0; i < DCMT_N_KERNEL_TIMES; ++i) DCMT_HIP(ctx, hipEventElapsedTime(&ms[i], ctx->tev[i], ctx->tev[i + 1]));
+    return DCMT_OK;
+}
 
 }  // extern "C"

@@ -269,6 +269,17 @@ int dcmt_last_holes_after_extend(dcmt_ctx *ctx, int *out, int n);
 
 const char *dcmt_strerror(int status);
 int dcmt_last_hip_error(const dcmt_ctx *ctx);
+
+/* Measurement aid (bench.py's live per-kernel split).  With timing on, the streaming path of every following *_dev call
+ * records HIP events on the caller's stream around its kernel groups (a few microseconds per call; off by default).
+ * dcmt_last_kernel_times synchronises with the last call's stream and returns milliseconds:
+ *   ms[0] the kernels in front of H5 that the call added (label-masked stage, normalisation scan; 0 for img_completion),
+ *   ms[1] k_pre_s (H2..H6, or H5..H6 behind the label stage),  ms[2] k_fp_s (H7..H11),
+ *   ms[3] the launches behind it (hole-closure redo / loop / recompute: near zero unless a frame needed the loop).
+ * DCMT_E_INVALID if timing was off for the last call or the call did not take the streaming path. */
+#define DCMT_N_KERNEL_TIMES 4
+int dcmt_set_kernel_timing(dcmt_ctx *ctx, int on);
+int dcmt_last_kernel_times(dcmt_ctx *ctx, float ms[DCMT_N_KERNEL_TIMES]);
 int dcmt_version(void);
 
 #ifdef __cplusplus

@@ -3,6 +3,7 @@ protocol, with world_size 2 over gloo (no GPU, no data-path collective to test: 
 import os
 import socket
 import subprocess
+import time
 import sys
 import textwrap
 
@@ -77,20 +78,48 @@ def test_two_rank_gloo_protocol(tmp_path):
     assert "OK" in outs[0][0]
 
 
+def _bench(nproc, *flags, timeout=300):
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
+    return subprocess.run(cmd + list(flags), capture_output=True, text=True, timeout=timeout)
+
+
 def test_bench_rank_protocol_two_ranks_gloo():
-    """bench.py's own multi-rank plumbing (env parsing, barriers, max over ranks, ONE JSON line from rank 0)
-    launched exactly as the driver launches it, with --dry-run replacing the GPU step."""
+    """bench.py's own multi-rank plumbing (env parsing, sharding of --total-frames, barriers, max over ranks, ONE JSON line from
+    rank 0) launched exactly as the driver launches it, with --dry-run replacing the GPU step."""
     import json
-    port = _free_port()
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "8", "--dry-run"], capture_output=True, text=True, timeout=300)
+    # the default: BASELINE configs[4] as written -- 1024 frames in total, sharded per frame (strong scaling)
+    r = _bench(2, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 8
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["total_frames_per_step"] == 1024 and d["config"]["frames_per_gpu_per_step"] == 512
     assert d["ms_per_step"] >= 4.0          # the slower rank (2 x 2 ms per step) sets the time
+    assert abs(d["value"] - 1024 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole-job frames over the slowest rank's time
+    # an uneven shard: 1001 frames on 2 ranks -> rank 0 owns 501
+    d = json.loads([l for l in _bench(2, "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-frames", "1001", "--dry-run").stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["frames_per_gpu_per_step"] == 501 and d["config"]["total_frames_per_step"] == 1001
+    # weak scaling on request, and labelled as such
+    r = _bench(2, "--gpus", "2", "--steps", "3", "--warmup", "1", "--weak", "--batch", "8", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 8 and d["config"]["total_frames_per_step"] == 16
     # a mismatch between --gpus and the launched world size is an error, not a silent single-GPU run
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120)
+    assert _bench(1, "--gpus", "2", "--dry-run", timeout=120).returncode != 0
+    # more ranks than frames is refused
+    assert _bench(1, "--gpus", "1", "--total-frames", "0", "--dry-run", timeout=120).returncode != 0
+
+
+def test_bench_failing_rank_ends_every_rank():
+    """A rank whose step failed (a frame that did not converge) must not leave the others waiting in a collective: the status
+    travels in the same all-reduce as the times, every rank exits non-zero, and no JSON line is printed."""
+    t0 = time.time()
+    r = _bench(2, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--dry-run-fail-rank", "1", timeout=240)
     assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 120

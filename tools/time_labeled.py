@@ -3,7 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from depth_completion_mt_amd import Context, make_params, synth
-for rows, cols, nt, B in ((352, 1216, 1200, 256), (375, 1242, 100, 256)):
+CONFIGS = {"2": (352, 1216, 1200, 256), "3": (375, 1242, 100, 256)}        # BASELINE configs[2] / [3]; LC_CONFIG=2|3 runs one of them
+for rows, cols, nt, B in [CONFIGS[k] for k in sorted(CONFIGS) if os.environ.get("LC_CONFIG", k) == k]:
     lab, nl = synth.synth_labels(rows, cols, nt, 0)
     d = torch.from_numpy(synth.synth_batch(8, rows, cols, 0)).cuda().repeat(B // 8, 1, 1).contiguous()
     dl = torch.from_numpy(lab).cuda()[None].repeat(B, 1, 1).contiguous()
