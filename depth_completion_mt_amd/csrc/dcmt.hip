@@ -16,6 +16,7 @@
 #include "dcmt.h"
 #include "dcmt_kernels_v1.h"
 #include "dcmt_kernels_fused.h"
+#include "dcmt_kernels_pair.h"
 #include "dcmt_kernels_slic.h"
 
 using namespace dcmt;
@@ -29,7 +30,7 @@ struct dcmt_ctx {
     float* pp[2] = {nullptr, nullptr};// ping-pong of the large-fill applications
     int* colstat = nullptr;           // [max_batch][tile rows][2][cols]  (staged path)
     int* counters = nullptr;          // [max_batch][kCntStride]
-    int* tcol = nullptr;              // [max_batch][max_cols]: first valid row of every X6 column (k_pre_s table mode -> k_fp_s)
+    int* tb = nullptr;                // [max_batch][2][max_cols]: first / last valid row of every X6 column (k_pre table mode -> k_fp_s)
     uint32_t* norm_stats = nullptr;   // [max_batch][2]  N1: order-preserving keys of each frame's max and (inverted) min
     float* norm_coef = nullptr;       // [max_batch][2]  N1: dst = src * a + b
     // host-entry staging (allocated on first use)
@@ -52,7 +53,9 @@ struct dcmt_ctx {
     int xcd_map = 1;                  // XCD-aware workgroup->frame mapping; env DCMT_XCD_MAP=0 disables
     int wide = 1;                     // LDS-DMA row loads where alignment allows; env DCMT_WIDE=0 disables
     int fuse_fp = 1;                  // H7..H11 in one kernel (k_fp_s); env DCMT_FUSE_FP=0 keeps k_fill_s + k_post_s
-    int top_table = 1;                // k_pre_s leaves the top extension zone of X6 unwritten, k_fp_s starts below it; env DCMT_TOP_TABLE=0 disables
+    int top_table = 1;                // k_pre leaves the extension zones of X6 unwritten, k_fp_s clamps its rows and starts below the top one; env DCMT_TOP_TABLE=0 disables
+    int pair = 1;                     // two columns per lane in H2..H6 (k_pre_p) where the width is even; env DCMT_PAIR=0 keeps k_pre_s
+    int bands = 0;                    // row bands per strip in k_pre_p (0 = by batch size); env DCMT_BANDS
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
@@ -222,7 +225,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         int* cnt = ctx->counters + (size_t)f0 * kCntStride;
         const float* cf = coef ? coef + 2 * (size_t)f0 : nullptr;
         // table mode: only the k_fp_s path reads X6 through the per-column table (the probes and the unfused kernels get a fully written X6)
-        int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tcol + (size_t)f0 * cols : nullptr;
+        int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tb + (size_t)f0 * 2 * cols : nullptr;
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
             // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
@@ -237,9 +240,39 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                                         rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
                 else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
                                         rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); }
-            if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
-            else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
+            // two columns per lane (k_pre_p) wherever a lane's 8-byte accesses are aligned: even width, 8-byte aligned frames
+            const bool pair = ctx->pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)(src16 ? (const void*)src16 : (const void*)src) % (src16 ? 4 : 8) == 0) &&
+                              ((uintptr_t)o6 % 8 == 0);
+            // row bands: full-height strips of a small batch leave most wave slots empty; bands need the (ti, bi) table
+            int bands = 1;
+            if (pair && tc) {
+                const int pstr = (cols + PreP<K0_AS_COMPILED, false>::VW - 1) / PreP<K0_AS_COMPILED, false>::VW;
+                bands = ctx->bands > 0 ? ctx->bands : ((long long)nb * pstr >= 2560 ? 1 : (int)((2560 + (long long)nb * pstr - 1) / ((long long)nb * pstr)));
+                if (bands > rows / 32) bands = rows / 32 > 0 ? rows / 32 : 1;
+                if (bands > 8) bands = 8;
+            }
+#define DCMT_PREP(KIND, WIDE) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
+                if (bands > 1) hipLaunchKernelGGL(k_tb_init, dim3(64), dim3(256), 0, st, tc, cols, nb); \
+                if (d_x4) { const int strips = (cols + G4::VW - 1) / G4::VW; \
+                    hipLaunchKernelGGL((k_pre_p<KIND, WIDE, true, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); } \
+                else { const int strips = (cols + G0::VW - 1) / G0::VW; \
+                    if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src16, o6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc); \
+                    else if (cf) hipLaunchKernelGGL((k_pre_p<KIND, WIDE, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
+                    else hipLaunchKernelGGL((k_pre_p<KIND, WIDE, false, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); } \
+                if (bands > 1) hipLaunchKernelGGL(k_tb_fix, dim3(64), dim3(256), 0, st, tc, o6, rows, cols, nb); }
+            if (pair) {
+                if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PREP(K0_AS_COMPILED, true) else DCMT_PREP(K0_AS_COMPILED, false) }
+                else { if (wide) DCMT_PREP(K0_DIAMOND, true) else DCMT_PREP(K0_DIAMOND, false) }
+            } else {
+                if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
+                else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
+            }
 #undef DCMT_PRE
+#undef DCMT_PREP
             DCMT_HIP(ctx, hipGetLastError());
             stamp(2);
             if (stop == DCMT_STAGE_EXTEND) continue;
@@ -601,6 +634,8 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }
     { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
     { const char* e = std::getenv("DCMT_LABEL_PAIRS"); if (e) ctx->label_pairs = std::atoi(e); }
     DeviceGuard dev_guard_(ctx);                    // allocate on the context's device, leave the caller's current device as it was
@@ -612,7 +647,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + FTH_FEW - 1) / FTH_FEW) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->tcol, sizeof(int) * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->tb, sizeof(int) * 2 * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->h_counters, sizeof(int) * (size_t)kCntStride * max_batch, hipHostMallocDefault) != hipSuccess)
@@ -627,7 +662,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     DeviceGuard dev_guard_(ctx);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
-    (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters); (void)hipFree(ctx->tcol);
+    (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters); (void)hipFree(ctx->tb);
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
     (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);

@@ -207,7 +207,7 @@ template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false, bool NOR
 __global__ __launch_bounds__(256)
 void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
-             int* __restrict__ tcol)
+             int* __restrict__ tb)
 {
     static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
@@ -387,15 +387,17 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     // ---- H6 (LO :122-127): rows >= last valid take its value, rows <= first valid take its
     // value; a column without valid pixels ends as 100 everywhere (:110, :125-127)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's own stores, before it reads two of them back
+    if (tb) {
+        // table mode (k_fp_s reads X6): the rows above a column's first valid row ti all equal row ti and the rows below its last
+        // valid row bi all equal row bi, so neither zone is written -- the reader clamps its row index into [ti, bi] instead
+        // (a third of X6 on velodyne-like frames stays out of HBM, both ways).  Table: [f][0][col] = ti, [f][1][col] = bi.  An
+        // empty column is 100 everywhere (LO :110, :125-127): both entries point at the last row, which gets the 100.
+        if (bi < 0) { ti = bi = rows - 1; ob.st(outlane ? oc : kDropOffset, rows - 1, cols, 100.0f); }
+        if (outlane) { tb[(size_t)f * 2 * cols + gx] = ti; tb[(size_t)f * 2 * cols + cols + gx] = bi; }
+        return;
+    }
     const float bv = ob.ld_at(oc + 4u * (unsigned)(max(bi, 0) * cols));
-    if (tcol) {
-        // table mode (k_fp_s reads X6): the rows above a column's first valid row all equal that row, so they are not written
-        // at all -- the reader clamps its row index to tcol[column] instead (a third of X6 on velodyne-like frames stays out of
-        // HBM, both ways).  An empty column is 100 everywhere: its table entry points at the last row, which holds the 100.
-        if (bi < 0) { ti = rows - 1; bi = rows; ob.st(outlane ? oc : kDropOffset, rows - 1, cols, 100.0f); }
-        if (outlane) tcol[(size_t)f * cols + gx] = ti;
-        if (!outlane) bi = rows;
-    } else {
+    {
         float tv = ob.ld_at(oc + 4u * (unsigned)(min(ti, rows - 1) * cols));
         if (bi < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
         if (!outlane) { ti = -1; bi = rows; }
@@ -829,7 +831,7 @@ __device__ __forceinline__ void row_scans3(float a, float b, float& pa, float& s
 
 __global__ __launch_bounds__(256)
 void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tcol)
+              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tb)
 {
     const int lane = threadIdx.x & 63;
     int f, sg;
@@ -846,9 +848,9 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     const float* sp = in + fo + gxc;
     float* op = out + fo + gxc;
     const int a_lo = ((lane - FillS::R) & 63) * 4, a_hi = ((lane + FillS::R) & 63) * 4;   // bpermute byte addresses
-    // tcol: `in` is an X6 whose rows above each column's first valid row were never written (k_pre_s, table mode): they
-    // equal that row, so the row index is clamped per lane
-    const int tl = tcol ? tcol[(size_t)f * cols + gxc] : 0;
+    // tb: `in` is an X6 whose extension zones were never written (k_pre_s / k_pre_p, table mode): the rows above a column's first
+    // valid row equal that row, the rows below its last valid row equal that one, so the row index is clamped per lane
+    const int tl = tb ? tb[(size_t)f * 2 * cols + gxc] : 0, bl = tb ? tb[(size_t)f * 2 * cols + cols + gxc] : rows - 1;
 
     // rolling rows, slot = row & 15 (16-step unroll keeps every index static)
     float PF[16], XC[16], W2[16], W4[16], W8[16], W16[16];
@@ -857,7 +859,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     // step t handles the (row-clamped) input row v = t - 15 and emits output row o = t - 30
     constexpr int PFD = 8;
 #pragma unroll
-    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)max(min(max(q - FillS::R, 0), rows - 1), tl) * cols];
+    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(min(max(q - FillS::R, 0), rows - 1), tl), bl) * cols];
     float vprev = -FLT_MAX;
     int before = 0, after = 0;
     const int nsteps = rows + 2 * FillS::R;
@@ -866,7 +868,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
         for (int p = 0; p < 16; ++p) {
             const int t = t0 + p;
             const float x = PF[p];
-            PF[(p + PFD) & 15] = sp[(size_t)max(min(max(t + PFD - FillS::R, 0), rows - 1), tl) * cols];
+            PF[(p + PFD) & 15] = sp[(size_t)min(max(min(max(t + PFD - FillS::R, 0), rows - 1), tl), bl) * cols];
             XC[p] = x;
             // vertical: windows ending at row t of 2, 4, 8, 16, 31 rows
             const float w2 = fmax2(x, vprev);
@@ -933,7 +935,7 @@ struct FpS {
 template <bool BLUR>
 __global__ __launch_bounds__(256)
 void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
-            int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tcol)
+            int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb)
 {
     // per wave, three 15-step delay lines: centre values, A's 16-row maxima (64 lanes each), B's 16-row
     // maxima (only its 30 halo lanes: packed to 32) -- 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
@@ -951,17 +953,18 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     // suffix the left side needs is a PREFIX over lanes too and one row scan serves both halos
     const int gxb = lane <= 14 ? gx0 + 64 + lane : (lane >= 49 ? gx0 + 48 - lane : (lane == 48 ? gx0 - 1 : gxa));
     const int gxac = min(max(gxa, 0), cols - 1), gxbc = min(max(gxb, 0), cols - 1);   // clamped: replicate == constant border for a max filter
-    // ---- the top extension zone.  k_pre_s (table mode) leaves the rows above each column's first valid row ti unwritten:
-    // they all equal row ti, so a row index is clamped per lane to ti.  With T = the smallest ti of the 94 columns this wave
-    // reads, rows 0 .. T of X6 are constant down every one of those columns and hole-free, hence so are X7 (rows <= T),
-    // the median (rows <= T - 2) and the output (rows <= T - 4, whichever border rule the top rows use).  The wave therefore
-    // treats row V = T - 8 as the top of its frame: the clamped row loads reproduce the real rows above V (they equal row V),
-    // the median's replicated and the Gaussian's reflected rows above V are rows of the constant zone like the real ones,
-    // and the first output row (V) is stored to rows 0 .. V-1 as well -- on velodyne-like frames (upper third empty) that is
-    // a quarter of the row steps of this kernel.
-    int tia = 0, tib = 0, V = 0;
-    if (tcol) {
-        tia = tcol[(size_t)f * cols + gxac]; tib = tcol[(size_t)f * cols + gxbc];
+    // ---- the extension zones.  In table mode k_pre_s / k_pre_p write neither the rows above a column's first valid row ti (they
+    // all equal row ti) nor the rows below its last valid row bi (they equal row bi): a row index is clamped per lane into
+    // [ti, bi].  With T = the smallest ti of the 94 columns this wave reads, rows 0 .. T of X6 are constant down every one of
+    // those columns and hole-free, hence so are X7 (rows <= T), the median (rows <= T - 2) and the output (rows <= T - 4,
+    // whichever border rule the top rows use).  The wave therefore treats row V = T - 8 as the top of its frame: the clamped
+    // row loads reproduce the real rows above V (they equal row V), the median's replicated and the Gaussian's reflected
+    // rows above V are rows of the constant zone like the real ones, and the first output row (V) is stored to rows
+    // 0 .. V-1 as well -- on velodyne-like frames (upper third empty) that is a quarter of the row steps of this kernel.
+    int tia = 0, tib = 0, bia = rows_all - 1, bib = rows_all - 1, V = 0;
+    if (tb) {
+        const int* tt = tb + (size_t)f * 2 * cols;
+        tia = tt[gxac]; tib = tt[gxbc]; bia = tt[cols + gxac]; bib = tt[cols + gxbc];
         V = __builtin_amdgcn_readfirstlane(max(wave_min_i(min(tia, tib)) - 8, 0));   // wave-uniform: keep the row arithmetic scalar
     }
     const int rows = rows_all - V;                                   // rows of the frame as this wave sees it (>= 9)
@@ -970,10 +973,11 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     const unsigned rowb = 4u * (unsigned)cols;
     const unsigned sba = 4u * (unsigned)gxac + (unsigned)V * rowb;   // byte offset of (row V, this lane's column)
     const unsigned sbb = 4u * (unsigned)gxbc + (unsigned)V * rowb;
-    const unsigned fla = 4u * (unsigned)gxac + (unsigned)max(tia, V) * rowb;   // no row above ti is ever read
-    const unsigned flb = 4u * (unsigned)gxbc + (unsigned)max(tib, V) * rowb;
-    auto ld_a = [&](int row) -> float { return sf.ld_at(max(sba + (unsigned)row * rowb, fla)); };   // row relative to V, already clamped to [0, rows)
-    auto ld_b = [&](int row) -> float { return sf.ld_at(max(sbb + (unsigned)row * rowb, flb)); };
+    const unsigned fla = 4u * (unsigned)gxac + (unsigned)max(tia, V) * rowb, cea = 4u * (unsigned)gxac + (unsigned)max(bia, V) * rowb;
+    const unsigned flb = 4u * (unsigned)gxbc + (unsigned)max(tib, V) * rowb, ceb = 4u * (unsigned)gxbc + (unsigned)max(bib, V) * rowb;
+    auto clamp3 = [](unsigned a, unsigned lo, unsigned hi) -> unsigned { return min(max(a, lo), hi); };     // v_med3_u32
+    auto ld_a = [&](int row) -> float { return sf.ld_at(clamp3(sba + (unsigned)row * rowb, fla, cea)); };   // row relative to V, already clamped to [0, rows)
+    auto ld_b = [&](int row) -> float { return sf.ld_at(clamp3(sbb + (unsigned)row * rowb, flb, ceb)); };
     const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
     const unsigned long long own_mask = __ballot(own);          // wave-uniform: the hole counts stay on the scalar unit
     const bool edge_strip = gx0 < 0 || gx0 + 63 >= cols;

@@ -1,0 +1,341 @@
+// dcmt_kernels_pair.h -- k_pre_p: H2..H6 (k_pre_s of dcmt_kernels_fused.h) with TWO adjacent columns per lane.
+//
+// A wave64 owns 128 columns over the full image height: lane l holds columns c0 + 2l ("E") and c0 + 2l + 1 ("O") in two
+// registers and streams down the rows like k_pre_s.  What that buys (both kernels are bound by VALU issue, and every
+// max / min / select / DPP instruction costs the same ~4.4 cycles whatever it does):
+//   * half of every horizontal window is already in the lane.  With m = max(E, O):
+//         3-window   E: max(O[l-1], m)            O: max(E[l+1], m)                      3 instructions per column pair (4)
+//         r -> r+1   E: max(W_O[l-1], W_O[l])     O: max(W_E[l+1], W_E[l])   (r >= 1)    2 instructions per column pair (4)
+//     so the 5-wide windows of the close cost 5 instead of 8 and the 7-wide window of the small fill 7 instead of 12,
+//     each [l-1] / [l+1] a DPP wave shift folded into the v_max / v_min;
+//   * the chain's reach (7 columns left, 9 right for the as-compiled element) costs 18 of 128 lanes-columns instead of
+//     20 of 64: 108 output columns per wave instead of 44;
+//   * rows arrive as 8 bytes per lane (one ds_read_b64 from the LDS-DMA ring, or buffer_load_dwordx2), and leave as one
+//     buffer_store_dwordx2.
+// Per row step: ~62 issue-bound instructions for 108 columns (k_pre_s: 41.5 for 44).
+//
+// Requires an even number of columns (a lane's two columns are both inside the image or both outside, its 8-byte accesses
+// are aligned); the LDS-DMA form (WIDE) needs cols % 4 == 0 and a 16-byte aligned frame.  Other shapes run k_pre_s.
+//
+// H6 (column extension): the zones above a column's first valid row ti and below its last valid row bi are constant down
+// the column.  In table mode (tb != nullptr) they are not written at all: the kernel records (ti, bi) per column and the
+// reader clamps its row index into [ti, bi] (k_fp_s, one v_med3 per load) -- a third of X6 never crosses HBM on
+// velodyne-like frames, and row bands of one strip (small batches) need no pass over each other's rows.  Without a
+// table the zones are written as the reference does (probes, stop_after, the unfused kernels).
+#pragma once
+
+#include "dcmt_kernels_fused.h"
+
+namespace dcmt {
+
+struct F2 { float e, o; };
+
+__device__ __forceinline__ F2 p_max(F2 a, F2 b) { return {fmax2(a.e, b.e), fmax2(a.o, b.o)}; }
+__device__ __forceinline__ F2 p_max3(F2 a, F2 b, F2 c) { return {fmax3(a.e, b.e, c.e), fmax3(a.o, b.o, c.o)}; }
+__device__ __forceinline__ F2 p_min3(F2 a, F2 b, F2 c) { return {fmin3(a.e, b.e, c.e), fmin3(a.o, b.o, c.o)}; }
+__device__ __forceinline__ F2 p_sel(bool c, F2 a, F2 b) { return {c ? a.e : b.e, c ? a.o : b.o}; }
+// windows over columns, for both columns of every lane
+__device__ __forceinline__ F2 p_hmax3(F2 v) { const float m = fmax2(v.e, v.o); return {fmax2(from_left(v.o), m), fmax2(from_right(v.e), m)}; }
+__device__ __forceinline__ F2 p_hmin3(F2 v) { const float m = fmin2(v.e, v.o); return {fmin2(from_left(v.o), m), fmin2(from_right(v.e), m)}; }
+__device__ __forceinline__ F2 p_grow_max(F2 w) { return {fmax2(from_left(w.o), w.o), fmax2(from_right(w.e), w.e)}; }   // radius r >= 1 -> r + 1
+__device__ __forceinline__ F2 p_grow_min(F2 w) { return {fmin2(from_left(w.o), w.o), fmin2(from_right(w.e), w.e)}; }
+
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// (cast the loaded vector as a whole: with hipcc 7.2, bit-casting its elements one by one -- bit_cast<float>(v.y) on the builtin's
+// result -- compiles to a ONE-dword load whose value serves as both elements)
+__device__ __forceinline__ F2 ld2(const FrameBuf& b, unsigned lane_bytes, int row, int cols)
+{
+    const f2v v = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(b.rs, lane_bytes, row * cols * 4, 0));
+    return {v.x, v.y};
+}
+__device__ __forceinline__ void st2(const FrameBuf& b, unsigned lane_bytes, int row, int cols, F2 v)
+{
+    const f2v f = {v.e, v.o};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f), b.rs, lane_bytes, row * cols * 4, 0);
+}
+
+// Wave-private LDS ring filled by LDS-DMA, 128 columns wide: one global_load_lds_dwordx4 moves 2 rows x 128 columns
+// (64 lanes x 16 B), a row is then one conflict-free ds_read_b64 per lane.  See RowRing for the rules.
+template <int SLOTS, int ROW_OFF>
+struct PairRing {
+    float* ring;            // SLOTS x 256 floats, this wave's
+    const float* src;       // frame base + clamped group column of this lane
+    int rows, cols, lrow;
+
+    __device__ __forceinline__ void init(float* wave_ring, const float* frame, int rows_, int cols_, int gx0, int lane)
+    {
+        ring = wave_ring; rows = rows_; cols = cols_;
+        lrow = lane >> 5;
+        src = frame + min(max(gx0 + 4 * (lane & 31), 0), cols_ - 4);
+    }
+    // stream rows 2*chunk, 2*chunk+1  ->  ring slot chunk % SLOTS
+    __device__ __forceinline__ void issue(int chunk) const
+    {
+        const int r = min(max(2 * chunk + lrow - ROW_OFF, 0), rows - 1);
+        const float* g = src + (size_t)r * cols;
+        float* l = ring + (chunk % SLOTS) * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    template <int KEEP>
+    __device__ __forceinline__ void wait() const { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); }
+    __device__ __forceinline__ F2 read(int s, int lane) const
+    {
+        const float2 v = *reinterpret_cast<const float2*>(ring + ((s >> 1) % SLOTS) * 256 + (s & 1) * 128 + 2 * lane);
+        return {v.x, v.y};
+    }
+};
+
+template <int K0KIND, bool START4>
+struct PreP {
+    // columns lost to the left / right of a strip: the chain's horizontal reach (k_pre_s has the derivation); START4 runs H5 only
+    static constexpr int HL0 = START4 ? 3 : (K0KIND == K0_AS_COMPILED ? 0 : 2) + 2 + 2 + 3;
+    static constexpr int HR0 = START4 ? 3 : 2 + 2 + 2 + 3;
+    static constexpr int HL = (HL0 + 3) / 4 * 4;                    // the strip origin is a multiple of 4 columns (16-byte LDS-DMA pieces)
+    static constexpr int VW = (128 - HL - HR0) / 4 * 4;             // output columns per wave, a multiple of 4 like HL: 108 (as compiled), 104 (diamond), 120 (START4)
+    static constexpr int LAT = 9;
+};
+
+// Row bands: with few frames a grid of full-height strips cannot fill the GPU (128 frames x 12 strips = 1536 waves for 4096
+// slots), so a strip may be cut into `bands` row ranges, one wave each.  A band starts its stream 18 rows above its first row
+// with cold rings (exactly like the start below the leading empty rows) and accounts for the x5 rows [r0, r1) only; the
+// per-column (ti, bi) of the bands are combined with atomicMin / atomicMax in the table (which the host initialises), which
+// is why bands need table mode.
+template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false, bool NORM = false>
+__global__ __launch_bounds__(256)
+void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips, int bands,
+             int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
+             int* __restrict__ tb)
+{
+    static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
+    static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
+    const float* src = static_cast<const float*>(src_);
+    using G = PreP<K0KIND, START4>;
+    constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
+    constexpr int SLOTS = 8, AHEAD = SLOTS - 1;  // ring slots per wave (2 rows x 128 columns each); blocks in flight
+    __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * SLOTS * 256 : 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int f, unit;
+    if (!wave_strip(blockIdx.x, wave, strips * bands, batch, xcd_map, f, unit)) return;   // whole waves leave; no barrier is used below
+    const int strip = unit / bands, band = unit - strip * bands;
+    const int gx0 = strip * G::VW - G::HL;
+    const int gx = gx0 + 2 * lane;                                   // column of E; O = gx + 1
+    const bool incol = gx >= 0 && gx < cols;                         // cols is even and gx is even: E and O are inside or outside together
+    const bool outlane = incol && 2 * lane >= G::HL && 2 * lane < G::HL + G::VW;
+    const size_t fo = (size_t)f * rows * cols;
+    const int gxc = min(max(gx, 0), cols - 2);
+    float na = 1.0f, nb = 0.0f;
+    if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
+    FrameBuf ob, ib;
+    ob.init(x6 + fo, (size_t)rows * cols);
+    if constexpr (U16) ib.init(reinterpret_cast<const float*>(static_cast<const uint16_t*>(src_) + fo), (size_t)rows * cols / 2);
+    else ib.init(src + fo, (size_t)rows * cols);
+    const unsigned oc = 4u * (unsigned)gxc;
+    auto load_row = [&](int r) -> F2 {            // image row r (already clamped) of this lane's two columns, in metres
+        if constexpr (U16) {
+            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(ib.rs, 2u * (unsigned)gxc, r * cols * 2, 0);
+            return {__fmul_rn((float)(w & 0xffffu), in_scale), __fmul_rn((float)(w >> 16), in_scale)};
+        } else {
+            return ld2(ib, oc, r, cols);
+        }
+    };
+    PairRing<SLOTS, ROFF> rr;
+    if constexpr (WIDE) rr.init(s_ring + wave * SLOTS * 256, src + fo, rows, cols, gx0, lane);
+
+    // rows this wave accounts for
+    const int r0 = (int)((long long)rows * band / bands), r1 = (int)((long long)rows * (band + 1) / bands);
+
+    constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
+    const F2 NEG2 = {NEG, NEG}, POS2 = {POS, POS};
+    F2 PF[8];                                    // prefetched input rows (plain loads)
+    float OX[8], S1E[8];                         // as compiled: x2 of the odd column, x2 of the even column of the next lane
+    F2 XR[8], A3[8];                             // diamond: x2 rows, horizontal 3-max rows
+    F2 H4[8], HE[8], H7[8], E4[8], T7[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { OX[q] = NEG; S1E[q] = NEG; XR[q] = NEG2; A3[q] = NEG2; H4[q] = NEG2; HE[q] = POS2; H7[q] = NEG2; E4[q] = NEG2; T7[q] = NEG2; PF[q] = {0.f, 0.f}; }
+    constexpr int PFD = 4;                       // rows of load lookahead (plain loads)
+
+    // ---- where the stream starts: below the leading empty rows (k_pre_s has the argument), or 18 rows above the band
+    int S = 0;
+    if (band > 0) S = max(r0 - 18, 0) & ~7;
+    else if constexpr (!START4) {
+        auto valid8 = [&](const F2 (&v)[8]) -> bool {
+            float m = fmax3(fmax3(fmax3(v[0].e, v[0].o, v[1].e), v[1].o, v[2].e), v[2].o, v[3].e);
+            m = fmax3(fmax3(fmax3(m, v[3].o, v[4].e), v[4].o, v[5].e), v[5].o, v[6].e);
+            m = fmax3(fmax3(m, v[6].o, v[7].e), v[7].o, m);
+            return __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;
+        };
+        auto load8 = [&](F2 (&v)[8], int z) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                F2 x = load_row(min(z + q, rows - 1));
+                if constexpr (NORM) x = {norm_apply(x.e, na, nb), norm_apply(x.o, na, nb)};
+                v[q] = x;
+            }
+        };
+        F2 va[8], vb[8];
+        int zv = r1;
+        load8(va, 0);
+        for (int z = 0; z < r1; z += 16) {         // two 8-row chunks per trip, the next one in flight while this one is looked at
+            load8(vb, z + 8);
+            if (valid8(va)) { zv = z; break; }
+            if (z + 8 >= r1) break;
+            load8(va, z + 16);
+            if (valid8(vb)) { zv = z + 8; break; }
+        }
+        S = max(zv - 18, 0) & ~7;
+    }
+    const int m0 = max(S > 0 ? S + 9 : 0, r0);   // first x5 row this wave accounts for
+
+    if constexpr (WIDE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scan's loads
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) rr.issue((S >> 1) + q);
+        rr.template wait<0>();                   // from here on the counted waits below see a fixed pattern of younger operations
+    } else {
+#pragma unroll
+        for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));
+    }
+
+    int tie = 0x7fffffff, tio = 0x7fffffff, bie = -1, bio = -1;   // first / last valid row of X5 in this lane's two columns (within the band)
+
+    const int nsteps = r1 + G::LAT;
+    for (int i0 = S; i0 < nsteps; i0 += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int i = i0 + p;
+            F2 raw;
+            if constexpr (WIDE) {
+                // one counter for loads and stores, in issue order; every step issues exactly one store, every second step one DMA:
+                // behind the block needed now there are AHEAD younger DMAs and 2 * AHEAD stores
+                if ((p & 1) == 0) { rr.issue((i >> 1) + AHEAD); rr.template wait<3 * AHEAD>(); }
+                raw = rr.read(i, lane);
+            } else {
+                raw = PF[p];
+                PF[(p + PFD) & 7] = load_row(min(max(i + PFD - ROFF, 0), rows - 1));
+            }
+            F2 e4;
+            const int l = i - 6;
+            if constexpr (START4) {
+                e4 = raw;                                               // X4 row l
+            } else {
+                if constexpr (NORM) raw = {norm_apply(raw.e, na, nb), norm_apply(raw.o, na, nb)};
+                // ---- H2 on load (LO :55-67); outside the image: the dilate border value
+                const bool in2 = incol && i < rows;
+                const F2 x2 = {in2 ? invert_valid(raw.e, max_depth, thr) : NEG, in2 ? invert_valid(raw.o, max_depth, thr) : NEG};
+                // ---- H3 (LO :71-80), row j = i - 2
+                const int j = i - 2;
+                F2 y3;
+                if constexpr (K0KIND == K0_AS_COMPILED) {
+                    // dst(r,c) = max(src(r-1,c+1), src(r+2,c+2)).  c = 2l: O[l] of row j-1, E[l+1] of row j+2; c = 2l+1: E[l+1] of row j-1, O[l+1] of row j+2
+                    const float s1e = from_right(x2.e);
+                    y3.e = fmax2(OX[(p + 5) & 7], s1e);
+                    y3.o = fmax2(from_right(x2.o), S1E[(p + 5) & 7]);
+                    OX[p] = x2.o;
+                    S1E[p] = s1e;
+                } else {
+                    // 13-tap diamond: rows j-2 and j+2 centre only, j-1 and j+1 three wide, j five wide
+                    const F2 a3 = p_hmax3(x2);
+                    XR[p] = x2;
+                    A3[p] = a3;
+                    const F2 a5j = p_grow_max(A3[(p + 6) & 7]);          // row j
+                    y3 = p_max(p_max3(XR[(p + 4) & 7] /* j-2 */, A3[(p + 5) & 7] /* j-1 */, a5j), p_max(A3[(p + 7) & 7] /* j+1 */, x2 /* j+2 */));
+                }
+                y3 = p_sel(incol && (unsigned)j < (unsigned)rows, y3, NEG2);
+                // ---- H4 dilate 5x5 (LO :85): horizontal on row j, vertical gives row k = j - 2
+                H4[(p + 6) & 7] = p_grow_max(p_hmax3(y3));
+                const int k = i - 4;
+                F2 d4 = p_max3(p_max3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
+                d4 = p_sel(incol && (unsigned)k < (unsigned)rows, d4, POS2);     // border value of the erode
+                // ---- H4 erode 5x5: row l = k - 2
+                HE[(p + 4) & 7] = p_grow_min(p_hmin3(d4));
+                e4 = p_min3(p_min3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+            }
+            e4 = p_sel(incol && (unsigned)l < (unsigned)rows, e4, NEG2);         // border value of the 7x7 dilate
+            E4[(p + 2) & 7] = e4;                                                // slot of row l = i-6
+            // ---- H5 (LO :88-100): dilate 7x7, row m = l - 3, then fill where x < 0.1
+            H7[(p + 2) & 7] = p_grow_max(p_grow_max(p_hmax3(e4)));
+            const int m = i - 9;
+            T7[p] = p_max3(H7[(p + 0) & 7], H7[(p + 1) & 7], H7[(p + 2) & 7]);   // rows i-8 .. i-6
+            const F2 d7 = p_max3(T7[p], T7[(p + 5) & 7] /* rows i-11 .. i-9 */, H7[(p + 4) & 7] /* row i-12 */);
+            const F2 e = E4[(p + 7) & 7];                                        // row m = i-9
+            const F2 x5 = {e.e < thr ? d7.e : e.e, e.o < thr ? d7.o : e.o};
+            const bool inrows = m >= m0 && m < r1;
+            if (inrows) {
+                // ---- H6 bookkeeping (LO :112-121): first / last row with x >= 0.1
+                const bool ve = x5.e >= thr, vo = x5.o >= thr;
+                tie = min(tie, ve ? m : 0x7fffffff); tio = min(tio, vo ? m : 0x7fffffff);
+                bie = ve ? m : bie; bio = vo ? m : bio;
+            }
+            // both columns leave in one 8-byte store once either has had its first valid row (what lands above a column's own first
+            // valid row is never read in table mode and rewritten by the epilogue otherwise); the store itself is issued on every
+            // step by every lane (the DMA waits count on it), aimed past the buffer when there is nothing to write
+            // (a band below the first one stores all its rows: the rows between a column's first valid row in an upper band and its
+            // first one here are real holes that the reader looks at)
+            st2(ob, (inrows && outlane && (band > 0 || m >= min(tie, tio))) ? oc : kDropOffset, inrows ? m : 0, cols, x5);
+        }
+    }
+    if (tb) {
+        // table mode: [f][0][col] = first valid row (rows - 1 for an empty column, whose last row gets the 100 of LO :110, :125-127),
+        // [f][1][col] = last valid row (same).  Bands combine by min / max; the host initialises the table.
+        int* tt = tb + (size_t)f * 2 * cols, *bt = tt + cols;
+        if (outlane) {
+            if (bands == 1) {
+                const bool ee = bie < 0, eo = bio < 0;
+                if (ee | eo) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ee) ob.st_at(oc + 4u * (unsigned)((rows - 1) * cols), 100.0f);
+                    if (eo) ob.st_at(oc + 4u + 4u * (unsigned)((rows - 1) * cols), 100.0f);
+                }
+                *reinterpret_cast<int2*>(tt + gx) = make_int2(ee ? rows - 1 : tie, eo ? rows - 1 : tio);
+                *reinterpret_cast<int2*>(bt + gx) = make_int2(ee ? rows - 1 : bie, eo ? rows - 1 : bio);
+            } else {
+                if (bie >= 0) { atomicMin(tt + gx, tie); atomicMax(bt + gx, bie); }
+                if (bio >= 0) { atomicMin(tt + gx + 1, tio); atomicMax(bt + gx + 1, bio); }
+            }
+        }
+        return;
+    }
+    // ---- H6 as the reference writes it (LO :122-127): rows >= last valid take its value, rows <= first valid take its
+    // value; a column without valid pixels ends as 100 everywhere (:110, :125-127).  One column at a time (4-byte stores).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's own stores, before it reads some of them back
+    auto extend = [&](unsigned cb, int ti, int bi) {
+        float tv = ob.ld_at(cb + 4u * (unsigned)(min(ti, rows - 1) * cols)), bv = ob.ld_at(cb + 4u * (unsigned)(max(bi, 0) * cols));
+        if (bi < 0) { ti = rows - 1; tv = 100.0f; bi = rows; }
+        if (!outlane) { ti = -1; bi = rows; }
+        const int tmax = wave_max_i(ti);
+        for (int r = 0; r <= tmax; ++r)
+            if (r <= ti) ob.st(cb, r, cols, tv);
+        const int bmin = wave_min_i(bi);
+        for (int r = bmin; r < rows; ++r)
+            if (r >= bi) ob.st(cb, r, cols, bv);
+    };
+    extend(oc, tie, bie);
+    extend(oc + 4u, tio, bio);
+}
+
+// Behind a banded k_pre_p: a column no band found a valid row in still holds the table's initial values.  It is 100
+// everywhere (LO :110, :125-127): point both entries at the last row and put the 100 there.
+__global__ void k_tb_fix(int* __restrict__ tb, float* __restrict__ x6, int rows, int cols, int batch)
+{
+    const size_t n = (size_t)batch * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / cols, c = i - f * cols;
+        int* tt = tb + f * 2 * cols;
+        if (tt[cols + c] < 0) {
+            tt[c] = rows - 1; tt[cols + c] = rows - 1;
+            x6[(f * rows + (rows - 1)) * cols + c] = 100.0f;
+        }
+    }
+}
+// table initialisation for banded launches: first rows = INT_MAX, last rows = -1
+__global__ void k_tb_init(int* __restrict__ tb, int cols, int batch)
+{
+    const size_t n = (size_t)batch * 2 * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        tb[i] = ((i / cols) & 1) ? -1 : 0x7fffffff;
+}
+
+}  // namespace dcmt
