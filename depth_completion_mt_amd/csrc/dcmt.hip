@@ -212,6 +212,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     stamp(1);
     const size_t fe = (size_t)rows * cols;
     const int chunk = (ctx->chunk > 0 && !sync_loop) ? ctx->chunk : batch;   // the host-synchronised loop works on the whole batch
+    const hipStream_t ps = st;
     const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
     int rc = DCMT_OK, apps_all = 0;
     for (int f0 = 0; f0 < batch; f0 += chunk) {
@@ -232,13 +233,13 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const bool wide = ctx->wide && cols % 4 == 0 && ((uintptr_t)src % 16 == 0) && !d_src16;
             const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr;
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
-                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
                                              rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); \
-                else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src16, o6, \
+                else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src16, o6, \
                                              rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc); \
-                else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
                                         rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
-                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), wave_grid(strips, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
                                         rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); }
             // two columns per lane (k_pre_p) wherever a lane's 8-byte accesses are aligned: even width, 8-byte aligned frames
             const bool pair = ctx->pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)(src16 ? (const void*)src16 : (const void*)src) % (src16 ? 4 : 8) == 0) &&
@@ -251,22 +252,21 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 if (bands > rows / 32) bands = rows / 32 > 0 ? rows / 32 : 1;
                 if (bands > 8) bands = 8;
             }
-#define DCMT_PREP(KIND, WIDE) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
-                if (bands > 1) hipLaunchKernelGGL(k_tb_init, dim3(64), dim3(256), 0, st, tc, cols, nb); \
+#define DCMT_PREP(KIND) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
+                if (bands > 1) hipLaunchKernelGGL(k_tb_init, dim3(64), dim3(256), 0, ps, tc, cols, nb); \
                 if (d_x4) { const int strips = (cols + G4::VW - 1) / G4::VW; \
-                    hipLaunchKernelGGL((k_pre_p<KIND, WIDE, true, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                    hipLaunchKernelGGL((k_pre_p<KIND, true, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
                                        rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); } \
                 else { const int strips = (cols + G0::VW - 1) / G0::VW; \
-                    if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src16, o6, \
+                    if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src16, o6, \
                                        rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc); \
-                    else if (cf) hipLaunchKernelGGL((k_pre_p<KIND, WIDE, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                    else if (cf) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
                                        rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
-                    else hipLaunchKernelGGL((k_pre_p<KIND, WIDE, false, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, st, (const void*)src, o6, \
+                    else hipLaunchKernelGGL((k_pre_p<KIND, false, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
                                        rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); } \
-                if (bands > 1) hipLaunchKernelGGL(k_tb_fix, dim3(64), dim3(256), 0, st, tc, o6, rows, cols, nb); }
+                if (bands > 1) hipLaunchKernelGGL(k_tb_fix, dim3(64), dim3(256), 0, ps, tc, o6, rows, cols, nb); }
             if (pair) {
-                if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PREP(K0_AS_COMPILED, true) else DCMT_PREP(K0_AS_COMPILED, false) }
-                else { if (wide) DCMT_PREP(K0_DIAMOND, true) else DCMT_PREP(K0_DIAMOND, false) }
+                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED) else DCMT_PREP(K0_DIAMOND)
             } else {
                 if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
                 else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }

@@ -10,12 +10,13 @@
 //     each [l-1] / [l+1] a DPP wave shift folded into the v_max / v_min;
 //   * the chain's reach (7 columns left, 9 right for the as-compiled element) costs 18 of 128 lanes-columns instead of
 //     20 of 64: 108 output columns per wave instead of 44;
-//   * rows arrive as 8 bytes per lane (one ds_read_b64 from the LDS-DMA ring, or buffer_load_dwordx2), and leave as one
-//     buffer_store_dwordx2.
+//   * rows arrive as 8 bytes per lane (buffer_load_dwordx2, 6 rows ahead) and leave as one buffer_store_dwordx2: 512-byte
+//     row segments.  (An LDS-DMA ring like k_pre_s's was measured too: 6 % slower here -- the plain loads already move whole
+//     lines, and the ring ties the loads' waits to the stores.)
 // Per row step: ~62 issue-bound instructions for 108 columns (k_pre_s: 41.5 for 44).
 //
 // Requires an even number of columns (a lane's two columns are both inside the image or both outside, its 8-byte accesses
-// are aligned); the LDS-DMA form (WIDE) needs cols % 4 == 0 and a 16-byte aligned frame.  Other shapes run k_pre_s.
+// are aligned).  Other shapes run k_pre_s.
 //
 // H6 (column extension): the zones above a column's first valid row ti and below its last valid row bi are constant down
 // the column.  In table mode (tb != nullptr) they are not written at all: the kernel records (ti, bi) per column and the
@@ -55,44 +56,12 @@ __device__ __forceinline__ void st2(const FrameBuf& b, unsigned lane_bytes, int 
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f), b.rs, lane_bytes, row * cols * 4, 0);
 }
 
-// Wave-private LDS ring filled by LDS-DMA, 128 columns wide: one global_load_lds_dwordx4 moves 2 rows x 128 columns
-// (64 lanes x 16 B), a row is then one conflict-free ds_read_b64 per lane.  See RowRing for the rules.
-template <int SLOTS, int ROW_OFF>
-struct PairRing {
-    float* ring;            // SLOTS x 256 floats, this wave's
-    const float* src;       // frame base + clamped group column of this lane
-    int rows, cols, lrow;
-
-    __device__ __forceinline__ void init(float* wave_ring, const float* frame, int rows_, int cols_, int gx0, int lane)
-    {
-        ring = wave_ring; rows = rows_; cols = cols_;
-        lrow = lane >> 5;
-        src = frame + min(max(gx0 + 4 * (lane & 31), 0), cols_ - 4);
-    }
-    // stream rows 2*chunk, 2*chunk+1  ->  ring slot chunk % SLOTS
-    __device__ __forceinline__ void issue(int chunk) const
-    {
-        const int r = min(max(2 * chunk + lrow - ROW_OFF, 0), rows - 1);
-        const float* g = src + (size_t)r * cols;
-        float* l = ring + (chunk % SLOTS) * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-    }
-    template <int KEEP>
-    __device__ __forceinline__ void wait() const { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); }
-    __device__ __forceinline__ F2 read(int s, int lane) const
-    {
-        const float2 v = *reinterpret_cast<const float2*>(ring + ((s >> 1) % SLOTS) * 256 + (s & 1) * 128 + 2 * lane);
-        return {v.x, v.y};
-    }
-};
-
 template <int K0KIND, bool START4>
 struct PreP {
     // columns lost to the left / right of a strip: the chain's horizontal reach (k_pre_s has the derivation); START4 runs H5 only
     static constexpr int HL0 = START4 ? 3 : (K0KIND == K0_AS_COMPILED ? 0 : 2) + 2 + 2 + 3;
     static constexpr int HR0 = START4 ? 3 : 2 + 2 + 2 + 3;
-    static constexpr int HL = (HL0 + 3) / 4 * 4;                    // the strip origin is a multiple of 4 columns (16-byte LDS-DMA pieces)
+    static constexpr int HL = (HL0 + 3) / 4 * 4;                    // strip origins are multiples of 4 columns: whole 16-byte pieces
     static constexpr int VW = (128 - HL - HR0) / 4 * 4;             // output columns per wave, a multiple of 4 like HL: 108 (as compiled), 104 (diamond), 120 (START4)
     static constexpr int LAT = 9;
 };
@@ -102,19 +71,17 @@ struct PreP {
 // with cold rings (exactly like the start below the leading empty rows) and accounts for the x5 rows [r0, r1) only; the
 // per-column (ti, bi) of the bands are combined with atomicMin / atomicMax in the table (which the host initialises), which
 // is why bands need table mode.
-template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false, bool NORM = false>
+template <int K0KIND, bool START4 = false, bool U16 = false, bool NORM = false>
 __global__ __launch_bounds__(256)
 void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips, int bands,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
              int* __restrict__ tb)
 {
-    static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
+    static_assert(!(U16 && START4), "the uint16 ingest is the first kernel of the path");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
     const float* src = static_cast<const float*>(src_);
     using G = PreP<K0KIND, START4>;
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
-    constexpr int SLOTS = 8, AHEAD = SLOTS - 1;  // ring slots per wave (2 rows x 128 columns each); blocks in flight
-    __shared__ __attribute__((aligned(16))) float s_ring[WIDE ? 4 * SLOTS * 256 : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int f, unit;
@@ -141,8 +108,6 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             return ld2(ib, oc, r, cols);
         }
     };
-    PairRing<SLOTS, ROFF> rr;
-    if constexpr (WIDE) rr.init(s_ring + wave * SLOTS * 256, src + fo, rows, cols, gx0, lane);
 
     // rows this wave accounts for
     const int r0 = (int)((long long)rows * band / bands), r1 = (int)((long long)rows * (band + 1) / bands);
@@ -155,49 +120,46 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     F2 H4[8], HE[8], H7[8], E4[8], T7[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { OX[q] = NEG; S1E[q] = NEG; XR[q] = NEG2; A3[q] = NEG2; H4[q] = NEG2; HE[q] = POS2; H7[q] = NEG2; E4[q] = NEG2; T7[q] = NEG2; PF[q] = {0.f, 0.f}; }
-    constexpr int PFD = 4;                       // rows of load lookahead (plain loads)
+#ifndef DCMT_PAIR_PFD
+#define DCMT_PAIR_PFD 6
+#endif
+    constexpr int PFD = DCMT_PAIR_PFD;           // rows of load lookahead (plain loads; the ring has 8 slots)
 
     // ---- where the stream starts: below the leading empty rows (k_pre_s has the argument), or 18 rows above the band
     int S = 0;
     if (band > 0) S = max(r0 - 18, 0) & ~7;
     else if constexpr (!START4) {
-        auto valid8 = [&](const F2 (&v)[8]) -> bool {
-            float m = fmax3(fmax3(fmax3(v[0].e, v[0].o, v[1].e), v[1].o, v[2].e), v[2].o, v[3].e);
-            m = fmax3(fmax3(fmax3(m, v[3].o, v[4].e), v[4].o, v[5].e), v[5].o, v[6].e);
-            m = fmax3(fmax3(m, v[6].o, v[7].e), v[7].o, m);
+        // 16-row chunks, two in flight: the scan is a chain of dependent round trips to memory, one per chunk
+        auto valid16 = [&](const F2 (&v)[16]) -> bool {
+            float m = fmax2(v[0].e, v[0].o);
+#pragma unroll
+            for (int q = 1; q < 16; q += 1) m = fmax3(m, v[q].e, v[q].o);
             return __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;
         };
-        auto load8 = [&](F2 (&v)[8], int z) {
+        auto load16 = [&](F2 (&v)[16], int z) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 F2 x = load_row(min(z + q, rows - 1));
                 if constexpr (NORM) x = {norm_apply(x.e, na, nb), norm_apply(x.o, na, nb)};
                 v[q] = x;
             }
         };
-        F2 va[8], vb[8];
+        F2 va[16], vb[16];
         int zv = r1;
-        load8(va, 0);
-        for (int z = 0; z < r1; z += 16) {         // two 8-row chunks per trip, the next one in flight while this one is looked at
-            load8(vb, z + 8);
-            if (valid8(va)) { zv = z; break; }
-            if (z + 8 >= r1) break;
-            load8(va, z + 16);
-            if (valid8(vb)) { zv = z + 8; break; }
+        load16(va, 0);
+        for (int z = 0; z < r1; z += 32) {
+            load16(vb, z + 16);
+            if (valid16(va)) { zv = z; break; }
+            if (z + 16 >= r1) break;
+            load16(va, z + 32);
+            if (valid16(vb)) { zv = z + 16; break; }
         }
         S = max(zv - 18, 0) & ~7;
     }
     const int m0 = max(S > 0 ? S + 9 : 0, r0);   // first x5 row this wave accounts for
 
-    if constexpr (WIDE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scan's loads
 #pragma unroll
-        for (int q = 0; q < AHEAD; ++q) rr.issue((S >> 1) + q);
-        rr.template wait<0>();                   // from here on the counted waits below see a fixed pattern of younger operations
-    } else {
-#pragma unroll
-        for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));
-    }
+    for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));
 
     int tie = 0x7fffffff, tio = 0x7fffffff, bie = -1, bio = -1;   // first / last valid row of X5 in this lane's two columns (within the band)
 
@@ -206,16 +168,8 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int i = i0 + p;
-            F2 raw;
-            if constexpr (WIDE) {
-                // one counter for loads and stores, in issue order; every step issues exactly one store, every second step one DMA:
-                // behind the block needed now there are AHEAD younger DMAs and 2 * AHEAD stores
-                if ((p & 1) == 0) { rr.issue((i >> 1) + AHEAD); rr.template wait<3 * AHEAD>(); }
-                raw = rr.read(i, lane);
-            } else {
-                raw = PF[p];
-                PF[(p + PFD) & 7] = load_row(min(max(i + PFD - ROFF, 0), rows - 1));
-            }
+            F2 raw = PF[p];
+            PF[(p + PFD) & 7] = load_row(min(max(i + PFD - ROFF, 0), rows - 1));
             F2 e4;
             const int l = i - 6;
             if constexpr (START4) {
