@@ -6,6 +6,7 @@
 // device every entry point fails with DCMT_E_NO_DEVICE / DCMT_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -65,6 +66,7 @@ struct dcmt_ctx {
     double* slic_centers[2] = {nullptr, nullptr};
     unsigned long long* slic_sums = nullptr;
     size_t slic_center_cap = 0;                 // centres per frame the two buffers above hold
+    int label_group = 0;              // LC fast path, two columns per lane: labels side by side per wave (0 = by label size); env DCMT_LABEL_GROUP
     int label_pairs = -1;             // LC fast path: one wave per label pair (1), per label (0), by label size (-1); env DCMT_LABEL_PAIRS
     int min_fused_batch = 12;         // smaller batches use the staged kernels (measured crossover: tools/batch_sweep.py); env DCMT_MIN_FUSED_BATCH
 };
@@ -414,6 +416,23 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             else
                 hipLaunchKernelGGL(k_label_bbox<false>, bg, dim3(256), 0, st, d_src, d_labels, n_labels, ctx->bb_min, ctx->bb_max, x4,
                                    rows, cols, p->max_depth, p->valid_thresh, coef);
+            // two columns per lane (k_label_stage_p) where a lane's 8-byte accesses are aligned; G labels side by side per wave, from the
+            // mean label area (a grown box of w + 10 columns takes (w + 10) / 2 + 1 lanes; SLIC-like labels are a few columns wider
+            // than the square root of their area)
+            const bool lpair = ctx->pair && cols % 2 == 0 && cols >= 8 && (uintptr_t)d_src % 8 == 0 && (uintptr_t)d_labels % 8 == 0 && (uintptr_t)x4 % 8 == 0;
+            int G = 1;
+            {
+                const double w = std::sqrt((double)rows * cols / n_labels) + 4.0;
+                const int lanes = (int)((w + 10.0) / 2.0) + 1;
+                G = (64 + lanes / 4) / (lanes > 0 ? lanes : 1);        // as many as fit side by side, rounded up when they nearly do (the rest gets a pass of its own)
+                if (G < 1) G = 1;
+                if (G > kLabelGroupMax) G = kLabelGroupMax;
+                if (ctx->label_group >= 1 && ctx->label_group <= kLabelGroupMax) G = ctx->label_group;
+            }
+            const int lwaves = (n_labels + G - 1) / G;
+            const dim3 lgp((lwaves + 3) / 4, batch);
+#define DCMT_LSTAGEP(KIND, NORM) hipLaunchKernelGGL((k_label_stage_p<KIND, NORM>), lgp, dim3(256), 0, st, d_src, d_labels, n_labels, G, \
+                                                   ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef)
             // labels of about 22 columns or less (the mean box of an even partition, with SLIC-like slack) can share a
             // wave: one wave per label PAIR; few large labels: one wave per label (see k_label_stage_s)
             const bool pairs = ctx->label_pairs >= 0 ? ctx->label_pairs != 0 : (double)rows * cols / n_labels <= 22.0 * 22.0;
@@ -422,9 +441,13 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
                                                    ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef); \
                                   else hipLaunchKernelGGL((k_label_stage_s<KIND, NORM, false>), lg, dim3(256), 0, st, d_src, d_labels, n_labels, \
                                                    ctx->bb_min, ctx->bb_max, x4, rows, cols, p->max_depth, p->valid_thresh, coef); }
-            if (kind == K0_AS_COMPILED) { if (coef) DCMT_LSTAGE(K0_AS_COMPILED, true) else DCMT_LSTAGE(K0_AS_COMPILED, false) }
+            if (lpair) {
+                if (kind == K0_AS_COMPILED) { if (coef) DCMT_LSTAGEP(K0_AS_COMPILED, true); else DCMT_LSTAGEP(K0_AS_COMPILED, false); }
+                else { if (coef) DCMT_LSTAGEP(K0_DIAMOND, true); else DCMT_LSTAGEP(K0_DIAMOND, false); }
+            } else if (kind == K0_AS_COMPILED) { if (coef) DCMT_LSTAGE(K0_AS_COMPILED, true) else DCMT_LSTAGE(K0_AS_COMPILED, false) }
             else { if (coef) DCMT_LSTAGE(K0_DIAMOND, true) else DCMT_LSTAGE(K0_DIAMOND, false) }
 #undef DCMT_LSTAGE
+#undef DCMT_LSTAGEP
             DCMT_HIP(ctx, hipGetLastError());
             if (stop == DCMT_STAGE_CLOSE5) {
                 ctx->last_stream = st; ctx->last_batch = batch; ctx->last_apps_launched = 0; ctx->last_has_loop = 0;
@@ -638,6 +661,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }
     { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
     { const char* e = std::getenv("DCMT_LABEL_PAIRS"); if (e) ctx->label_pairs = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_LABEL_GROUP"); if (e) ctx->label_group = std::atoi(e); }
     DeviceGuard dev_guard_(ctx);                    // allocate on the context's device, leave the caller's current device as it was
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (dev_guard_.rc != DCMT_OK) return fail(dev_guard_.rc);

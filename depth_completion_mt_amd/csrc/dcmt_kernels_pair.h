@@ -293,3 +293,187 @@ __global__ void k_tb_init(int* __restrict__ tb, int cols, int batch)
 }
 
 }  // namespace dcmt
+
+namespace dcmt {
+
+// ---------------------------------------------------------------------------------
+// LC variant, label-masked stage with two columns per lane (k_label_stage_s of dcmt_kernels_fused.h has the scheme:
+// LC/img_completion_lc.cpp:78-102 -- for every label c: region = x * [label == c]; region = erode5(dilate5(dilate_k0(region)));
+// x[label == c] = region[label == c]).  A wave64 runs the masked H2..H4 pipeline for up to four labels side by side: every
+// label's bounding box, grown by the chain's reach (4 / 6 columns left / right for the as-compiled element, 6 / 6 for the
+// diamond) and aligned to an even column, is a segment of lane PAIRS, so a 22-column superpixel takes 16-17 lanes instead
+// of 32 and the horizontal windows cost what they cost in k_pre_p.  Lanes carry their own label, image rows and columns;
+// the DPP shifts that cross a segment boundary only ever reach halo columns (outside the label's box, so never written:
+// the write-back is masked by label == c, and a label's pixels all lie inside its box).
+// Rows: a label's pixels lie in rows y0 .. y1, so the masked image is all zero above y0 and below y1.  If every label of the
+// pass starts at least 10 rows below the image top, the stream starts AT y0 with the rings holding what six all-zero rows
+// leave behind (zeros: max / min of zeros; no border value is within reach) instead of six rows above it: h + 6 row steps
+// per label instead of h + 12.
+// G labels per wave (host: by mean label area); a group that does not fit in 64 lanes runs in several passes, a box wider
+// than one pass (116 columns) in chunks.  Any G is correct for any label plane.  Measured (1216x352, 1360 labels of ~22 columns,
+// 256 frames): G = 1 / 2 / 3 / 4 -> 1.43 / 0.87 / 0.61 / 0.54 ms; giving a wave MORE labels than fit side by side (6, 8: two or
+// three passes per wave, fewer waves) is slower again (0.69 / 0.62 ms): the passes are short (h + 6 row steps) and bound by
+// the latency of their first rows, so many short waves beat fewer long ones.
+// ---------------------------------------------------------------------------------
+// INTERIOR: every row and column the pass touches lies inside the image (and the stream starts warm): no border value can
+// appear, so the border selects go away and the row addresses advance by one fast add per step instead of clamp + multiply.
+template <int K0KIND, bool NORM, bool INTERIOR>
+__device__ __forceinline__ void label_pipeline_p(const FrameBuf& sb, const FrameBuf& lb, const FrameBuf& ob, int L, int y0, int gx, int ox0, int ox1,
+                                                 bool warm, int nsteps, int rows, int cols, float max_depth, float thr, float na, float nb)
+{
+    constexpr float NEG = -FLT_MAX, POS = FLT_MAX;
+    const F2 NEG2 = {NEG, NEG}, POS2 = {POS, POS}, Z2 = {0.f, 0.f};
+    const bool incol = gx >= 0 && gx < cols;                     // gx and cols are even: both columns inside or both outside
+    const bool oute = incol && gx >= ox0 && gx <= ox1, outo = incol && gx + 1 >= ox0 && gx + 1 <= ox1;   // columns this pass may write
+    const unsigned gb = 4u * (unsigned)min(max(gx, 0), cols - 2);
+    const unsigned rowb = 4u * (unsigned)cols;
+    auto row_off = [&](int r) -> unsigned { return gb + rowb * (unsigned)min(max(r, 0), rows - 1); };
+    F2 PF[8], H4[8], HE[8], XR[8], A3[8];
+    float OX[8], S1E[8];
+    int PLe[8], PLo[8], LBe[8], LBo[8];
+    const bool w = INTERIOR || warm;
+    const F2 h4i = w ? Z2 : NEG2, hei = w ? Z2 : POS2;
+    const float s0i = w ? 0.f : NEG;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { PF[q] = Z2; H4[q] = h4i; HE[q] = hei; XR[q] = {s0i, s0i}; A3[q] = {s0i, s0i}; OX[q] = s0i; S1E[q] = s0i; PLe[q] = PLo[q] = LBe[q] = LBo[q] = -1; }
+    const int rs = w ? y0 : y0 - 6;                // image row of step 0
+    constexpr int PFD = 4;
+    // INTERIOR: wa = byte offset of (row i - 6, this lane's columns), the row written in step i; the loads reach ahead of it
+    // through the scalar offset.  (rs >= 10, so wa never goes below the frame.)
+    unsigned wa = gb + rowb * (unsigned)(rs - 6);
+    auto fetch = [&](int slot, int r, int ahead) {
+        unsigned vo, so;
+        if constexpr (INTERIOR) { vo = wa; so = rowb * (unsigned)(6 + ahead); } else { vo = row_off(r); so = 0; }
+        const f2v v = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(sb.rs, vo, so, 0));
+        const int2 li = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(lb.rs, vo, so, 0));
+        PF[slot] = {v.x, v.y}; PLe[slot] = li.x; PLo[slot] = li.y;
+    };
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) fetch(q, rs + q, q);
+    for (int s0 = 0; s0 < nsteps; s0 += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int i = rs + (s0 + p);             // image row fed by this step (per lane)
+            F2 raw = PF[p];
+            const int le = PLe[p], lo = PLo[p];
+            fetch((p + PFD) & 7, i + PFD, PFD);
+            LBe[p] = le; LBo[p] = lo;
+            // masked copy (LC :94-95): the label's pixels keep their H2 value, other image pixels are 0; outside the image the dilate border value
+            if constexpr (NORM) raw = {norm_apply(raw.e, na, nb), norm_apply(raw.o, na, nb)};
+            F2 x2 = {le == L ? invert_valid(raw.e, max_depth, thr) : 0.0f, lo == L ? invert_valid(raw.o, max_depth, thr) : 0.0f};
+            if constexpr (!INTERIOR) x2 = p_sel(incol && (unsigned)i < (unsigned)rows, x2, NEG2);
+            const int j = i - 2;
+            F2 y3;
+            if constexpr (K0KIND == K0_AS_COMPILED) {
+                const float s1e = from_right(x2.e);
+                y3.e = fmax2(OX[(p + 5) & 7], s1e);
+                y3.o = fmax2(from_right(x2.o), S1E[(p + 5) & 7]);
+                OX[p] = x2.o;
+                S1E[p] = s1e;
+            } else {
+                const F2 a3 = p_hmax3(x2);
+                XR[p] = x2;
+                A3[p] = a3;
+                const F2 a5j = p_grow_max(A3[(p + 6) & 7]);
+                y3 = p_max(p_max3(XR[(p + 4) & 7], A3[(p + 5) & 7], a5j), p_max(A3[(p + 7) & 7], x2));
+            }
+            if constexpr (!INTERIOR) y3 = p_sel(incol && (unsigned)j < (unsigned)rows, y3, NEG2);
+            H4[(p + 6) & 7] = p_grow_max(p_hmax3(y3));
+            const int k = i - 4;
+            F2 d4 = p_max3(p_max3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
+            if constexpr (!INTERIOR) d4 = p_sel(incol && (unsigned)k < (unsigned)rows, d4, POS2);
+            HE[(p + 4) & 7] = p_grow_min(p_hmin3(d4));
+            const int l = i - 6;
+            const F2 e4 = p_min3(p_min3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+            // write-back only where the label is this one (LC :101): a 4-byte store per column, aimed past the buffer where it is not
+            // (a row l outside the image is never written: the clamped loads' labels are not consulted for it)
+            if constexpr (INTERIOR) {
+                ob.st_at((oute && LBe[(p + 2) & 7] == L) ? wa : kDropOffset, e4.e);
+                ob.st_at((outo && LBo[(p + 2) & 7] == L) ? wa + 4u : kDropOffset, e4.o);
+                wa += rowb;
+            } else {
+                const bool inl = (unsigned)l < (unsigned)rows;
+                const unsigned wo = gb + rowb * (unsigned)l;
+                ob.st_at((inl && oute && LBe[(p + 2) & 7] == L) ? wo : kDropOffset, e4.e);
+                ob.st_at((inl && outo && LBo[(p + 2) & 7] == L) ? wo + 4u : kDropOffset, e4.o);
+            }
+        }
+    }
+}
+
+constexpr int kLabelGroupMax = 4;     // labels one wave may be given (it runs them in passes of as many as fit side by side)
+template <int K0KIND, bool NORM>
+__global__ __launch_bounds__(256)
+void k_label_stage_p(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels, int G,
+                     const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
+                     int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
+{
+    constexpr int HL = K0KIND == K0_AS_COMPILED ? 4 : 6, HR = 6, H = 6;
+    constexpr int VW = (128 - HL - HR - 1) & ~1;         // output columns of one chunk of a box wider than a wave
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int first = wv * G, last = min(first + G, n_labels);      // this wave's labels
+    if (first >= n_labels) return;
+    const int f = blockIdx.y;
+    const size_t bo = (size_t)f * n_labels;
+    const size_t fo = (size_t)f * rows * cols, fe = (size_t)rows * cols;
+    float na = 1.0f, nb = 0.0f;
+    if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
+    FrameBuf sb, lb, ob;
+    sb.init(src + fo, fe);
+    lb.init(reinterpret_cast<const float*>(labels + fo), fe);
+    ob.init(x4 + fo, fe);
+    // the boxes of this wave's (at most kLabelGroupMax) labels, fetched together: one round trip to memory, not one per label
+    int by0[kLabelGroupMax], bx0[kLabelGroupMax], by1[kLabelGroupMax], bx1[kLabelGroupMax];
+#pragma unroll
+    for (int q = 0; q < kLabelGroupMax; ++q) {
+        const int c = min(first + q, n_labels - 1);
+        const int2 mn = *reinterpret_cast<const int2*>(bb_min + (bo + c) * 2), mx = *reinterpret_cast<const int2*>(bb_max + (bo + c) * 2);
+        by0[q] = mn.x; bx0[q] = mn.y; by1[q] = first + q < last ? mx.x : -1; bx1[q] = mx.y;
+    }
+    int k = 0;                                       // next label of the wave (index into the arrays above); G <= kLabelGroupMax
+    int cx = 0, cj = -1;                             // a box being walked in chunks: next chunk's first column, its label index
+    const int nl = last - first;
+    while (k < nl || cj >= 0) {
+        int L = -2, y0 = 0, gx = -2, ox0 = 0, ox1 = -1;  // lanes without a segment: no label, outside the image
+        int hmax = 0, ymin = 0x7fffffff, ymax = -1, xlo = 0x7fffffff, xhi = -1;   // of the pass: tallest box, first / last starting row, first / last column touched
+        if (cj >= 0) {
+            const int sx = (cx - HL) & ~1;
+            L = first + cj; y0 = by0[cj]; gx = sx + 2 * lane; ox0 = cx; ox1 = min(cx + VW - 1, bx1[cj]);
+            hmax = by1[cj] - by0[cj] + 1; ymin = ymax = by0[cj]; xlo = sx; xhi = sx + 127;
+            cx += VW;
+            if (cx > bx1[cj]) cj = -1;
+        } else {
+            // pack labels k, k+1, ... side by side, in order, while their segments fit in 64 lanes
+            int used = 0, nseg = 0;
+            bool full = false;
+#pragma unroll
+            for (int q = 0; q < kLabelGroupMax; ++q) {
+                if (full || q < k || q >= nl) continue;
+                if (by1[q] >= 0) {                                   // (a label may own no pixel: skipped)
+                    const int sx = (bx0[q] - HL) & ~1;
+                    const int need = ((bx1[q] + HR - sx) >> 1) + 1;
+                    if (used + need > 64) { full = true; continue; }
+                    if (lane >= used && lane < used + need) { L = first + q; y0 = by0[q]; gx = sx + 2 * (lane - used); ox0 = bx0[q]; ox1 = bx1[q]; }
+                    used += need; ++nseg;
+                    hmax = max(hmax, by1[q] - by0[q] + 1); ymin = min(ymin, by0[q]); ymax = max(ymax, by0[q]);
+                    xlo = min(xlo, sx); xhi = max(xhi, sx + 2 * need - 1);
+                }
+                k = q + 1;
+            }
+            if (nseg == 0) {
+                if (k >= nl) break;                                   // only empty labels were left
+                cj = k; cx = bx0[k]; ++k;                             // label k alone is wider than a wave: walk its box in chunks
+                continue;
+            }
+        }
+        const bool warm = ymin >= 10;
+        const int nsteps = hmax + (warm ? H : 2 * H);
+        // interior pass: warm, every column touched inside the image, every row fed or prefetched inside it
+        const bool interior = warm && xlo >= 0 && xhi < cols && ymax + nsteps + 7 + 4 < rows;   // (the step loop runs in eights, the loads 4 rows ahead)
+        if (interior) label_pipeline_p<K0KIND, NORM, true>(sb, lb, ob, L, y0, gx, ox0, ox1, true, nsteps, rows, cols, max_depth, thr, na, nb);
+        else label_pipeline_p<K0KIND, NORM, false>(sb, lb, ob, L, y0, gx, ox0, ox1, warm, nsteps, rows, cols, max_depth, thr, na, nb);
+    }
+}
+
+}  // namespace dcmt

@@ -1,4 +1,5 @@
-"""frames/s of the label-masked variant (BASELINE configs 3 and 4) on device-resident batches."""
+"""frames/s of the label-masked variant (BASELINE configs 2 and 3) on device-resident batches, with the library's own
+per-kernel-group events (label stage = k_label_bbox + k_label_stage_*; k_pre = H5..H6 behind it; k_fp_s)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,5 +18,8 @@ for rows, cols, nt, B in [CONFIGS[k] for k in sorted(CONFIGS) if os.environ.get(
     for _ in range(n): ctx.complete_dev(d, o, p, d_labels=dl, n_labels=nl)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"labeled {cols}x{rows}, {nl} labels, batch {B}: {B * n / dt:.0f} frames/s ({dt / n * 1e3:.2f} ms per batch)")
+    ctx.set_kernel_timing(True)
+    ctx.complete_dev(d, o, p, d_labels=dl, n_labels=nl)
+    kt = {k: round(v, 4) for k, v in ctx.last_kernel_times().items()}
+    print(f"labeled {cols}x{rows}, {nl} labels, batch {B}: {B * n / dt:.0f} frames/s ({dt / n * 1e3:.3f} ms per batch) {kt}", {k: v for k, v in os.environ.items() if k.startswith("DCMT_")})
     ctx.close()
