@@ -43,8 +43,8 @@ python bench.py --batch1 --no-cpu-baseline --no-configs > $SUM/${TAG}_bench_batc
 f() { find $OUT/$1 -name "*$2" | head -1; }
 cp "$(f stats kernel_stats.csv)" $SUM/${TAG}_kernel_stats.csv
 cp "$(f lc kernel_stats.csv)" $SUM/${TAG}_lc_kernel_stats.csv
-for n in n1 n2 n3 n4; do cp "$(f $n kernel_stats.csv)" $SUM/${TAG}_${n}_kernel_stats.csv; tail -n 4 $OUT/$n.log > $SUM/${TAG}_${n}_tool_output.txt; done
-tail -n 4 $OUT/lc.log > $SUM/${TAG}_lc_tool_output.txt
+for n in n1 n2 n3 n4; do cp "$(f $n kernel_stats.csv)" $SUM/${TAG}_${n}_kernel_stats.csv; grep -E "frames/s| ms|pairs/s|sweeps/s|per image" $OUT/$n.log > $SUM/${TAG}_${n}_tool_output.txt || true; done
+grep -E "frames/s" $OUT/lc.log > $SUM/${TAG}_lc_tool_output.txt || true
 python tools/pmc_traffic.py "$(f fetch counter_collection.csv)" "$(f write counter_collection.csv)" 8 $SUM/${TAG}_traffic.json > /dev/null
 for c in 2 3; do
 python tools/pmc_traffic.py "$(f lc${c}_fetch counter_collection.csv)" "$(f lc${c}_write counter_collection.csv)" 7 $SUM/${TAG}_lc_config${c}_traffic.json > /dev/null
