@@ -783,9 +783,8 @@ int dcmt_stereo_refine_dev(dcmt_ctx* ctx, const float* d_depth, const uint8_t* d
     if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
     if (params->iterations > 1000) return DCMT_E_INVALID;
     StereoP P{params->baseline, params->focal, params->damp, params->max_depth, params->iterations < 0 ? 4 : params->iterations};
-    size_t blocks = ((size_t)batch * rows * cols + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_stereo_refine, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_depth, d_left, d_right, d_refined,
+    if (rows > 65535 || batch > 65535) return DCMT_E_INVALID;                  // grid dimensions y, z
+    hipLaunchKernelGGL(k_stereo_refine, dim3((cols + 255) / 256, rows, batch), dim3(256), 0, (hipStream_t)stream, d_depth, d_left, d_right, d_refined,
                        rows, cols, batch, P);
     DCMT_HIP(ctx, hipGetLastError());
     return DCMT_OK;

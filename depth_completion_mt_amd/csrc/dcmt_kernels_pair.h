@@ -126,9 +126,12 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     constexpr int PFD = DCMT_PAIR_PFD;           // rows of load lookahead (plain loads; the ring has 8 slots)
 
     // ---- where the stream starts: below the leading empty rows (k_pre_s has the argument), or 18 rows above the band
+    // START4 (the input is X4, only H5 runs): x5(m) reaches X4 rows m-3 .. m+3 and step i feeds X4 row i - 6 while finishing x5 row
+    // i - 9, so the stream may start at step zv itself and its x5 rows are exact from S - 3 on.
+    constexpr int DZ = START4 ? 0 : 18, DM = START4 ? -3 : 9;
     int S = 0;
     if (band > 0) S = max(r0 - 18, 0) & ~7;
-    else if constexpr (!START4) {
+    else {
         // 16-row chunks, two in flight: the scan is a chain of dependent round trips to memory, one per chunk
         auto valid16 = [&](const F2 (&v)[16]) -> bool {
             float m = fmax2(v[0].e, v[0].o);
@@ -154,9 +157,9 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             load16(va, z + 32);
             if (valid16(vb)) { zv = z + 16; break; }
         }
-        S = max(zv - 18, 0) & ~7;
+        S = max(zv - DZ, 0) & ~7;
     }
-    const int m0 = max(S > 0 ? S + 9 : 0, r0);   // first x5 row this wave accounts for
+    const int m0 = max(S > 0 ? S + (band > 0 ? 9 : DM) : 0, r0);   // first x5 row this wave accounts for
 
 #pragma unroll
     for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));

@@ -205,41 +205,51 @@ __device__ __forceinline__ float grey_dx(const uint8_t* g, int r, int c, int row
     return __fsub_rn(__fmul_rn(0.5f, (float)g[(size_t)r * cols + c + 1]), __fmul_rn(0.5f, (float)g[(size_t)r * cols + c - 1]));
 }
 
+// Grid: (ceil(cols / 256), rows, batch) -- one thread per pixel, no index divisions.  Per Gauss-Newton sweep the reference
+// touches six right-image bytes (p00, p01 and the central differences at both); p01 is the neighbour of p00 in memory
+// (e1 = e0 + 1, also across the end of a row, which the reference's at<>() reads too), so the six are four distinct bytes:
+// g[e0-1], g[e0], g[e1], g[e1+1].  All arithmetic as in the oracle: one rounding per operation, IEEE divisions where the
+// reference divides (initial disparity, every sweep's step, final depth).
 __global__ __launch_bounds__(256)
 void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                      float* __restrict__ out, int rows, int cols, int batch, StereoP P)
 {
-    const size_t fe = (size_t)rows * cols, n = fe * batch;
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= cols) return;
+    const size_t fe = (size_t)rows * cols, idx = (size_t)blockIdx.z * fe + (size_t)i * cols + j;
+    const int fei = (int)fe;                                                    // a frame has < 2^29 pixels (dcmt_create)
     const float bf = __fmul_rn(P.baseline, P.focal);
-    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-        const size_t f = idx / fe, rem = idx - f * fe;
-        const int i = (int)(rem / cols), j = (int)(rem - (size_t)i * cols);
-        const uint8_t* gr = right + f * fe;
-        const float d0 = depth[idx];
-        float disp = d0 > 0.0f ? __fdiv_rn(bf, d0) : 0.0f;                      // get_initial_disparity :852-856
-        const float lv = (float)left[idx];
-        for (int k = 0; k < P.iterations; ++k) {                                // optimize_IG :809-841
-            const float c = __fsub_rn((float)j, disp);
-            const int c0 = (int)((double)c + 0.5);
-            if (c0 < 0 || c0 + 1 > cols || disp == 0.0f) continue;
-            const size_t e0 = (size_t)i * cols + c0, e1 = e0 + 1;              // p00, p01 (p01 may be the next row's first pixel)
-            if (e1 >= fe) continue;
-            const int r1 = (int)(e1 / cols), c1 = (int)(e1 - (size_t)r1 * cols);
-            const float dc = __fsub_rn(c, (float)c0), dc1 = __fsub_rn(1.0f, dc);
-            const float value = __fadd_rn(__fmul_rn((float)gr[e0], dc1), __fmul_rn((float)gr[e1], dc));
-            const float dx = __fadd_rn(__fmul_rn(grey_dx(gr, i, c0, rows, cols), dc1), __fmul_rn(grey_dx(gr, r1, c1, rows, cols), dc));
-            float error = __fsub_rn(value, lv);                                 // :819
-            error = error > 255.0f ? 255.0f : error;
-            error = error < -255.0f ? -255.0f : error;
-            const float jcr = __fmul_rn(-1.0f, dx);                             // J = -1 (:830-832)
-            const float H = __fadd_rn(__fmul_rn(jcr, jcr), P.damp);
-            const float b = __fmul_rn(jcr, error);
-            disp = __fadd_rn(disp, __fdiv_rn(-b, H));                           // :836-837
-        }
-        float o = 0.0f;                                                         // retrieve_optimized_depth :868-880
-        if (disp > 0.0f) { o = __fdiv_rn(bf, disp); if (o > P.max_depth) o = P.max_depth; }
-        out[idx] = o;
+    const uint8_t* gr = right + (size_t)blockIdx.z * fe;
+    const float d0 = depth[idx];
+    float disp = d0 > 0.0f ? __fdiv_rn(bf, d0) : 0.0f;                          // get_initial_disparity :852-856
+    const float lv = (float)left[idx];
+    const bool row_in = i >= 1 && i < rows - 1;
+    for (int k = 0; k < P.iterations; ++k) {                                    // optimize_IG :809-841
+        const float c = __fsub_rn((float)j, disp);
+        const int c0 = (int)((double)c + 0.5);
+        if (c0 < 0 || c0 + 1 > cols || disp == 0.0f) continue;
+        const int e0 = i * cols + c0, e1 = e0 + 1;                              // p00, p01 (p01 may be the next row's first pixel)
+        if (e1 >= fei) continue;
+        const bool wrap = c0 + 1 == cols;                                       // p01 = (i + 1, 0)
+        const float g0 = (float)gr[e0], g1 = (float)gr[e1];
+        // central differences (calculateMeasuementDerivatives :715-745): 0 on the image border
+        float dx0 = 0.0f, dx1 = 0.0f;
+        if (row_in && c0 >= 1 && c0 < cols - 1) dx0 = __fsub_rn(__fmul_rn(0.5f, g1), __fmul_rn(0.5f, (float)gr[e0 - 1]));
+        if (!wrap && row_in && c0 + 1 < cols - 1) dx1 = __fsub_rn(__fmul_rn(0.5f, (float)gr[e1 + 1]), __fmul_rn(0.5f, g0));   // (a wrapped p01 sits in column 0: border, 0)
+        const float dc = __fsub_rn(c, (float)c0), dc1 = __fsub_rn(1.0f, dc);
+        const float value = __fadd_rn(__fmul_rn(g0, dc1), __fmul_rn(g1, dc));
+        const float dx = __fadd_rn(__fmul_rn(dx0, dc1), __fmul_rn(dx1, dc));
+        float error = __fsub_rn(value, lv);                                     // :819
+        error = error > 255.0f ? 255.0f : error;
+        error = error < -255.0f ? -255.0f : error;
+        const float jcr = __fmul_rn(-1.0f, dx);                                 // J = -1 (:830-832)
+        const float H = __fadd_rn(__fmul_rn(jcr, jcr), P.damp);
+        const float b = __fmul_rn(jcr, error);
+        disp = __fadd_rn(disp, __fdiv_rn(-b, H));                               // :836-837
     }
+    float o = 0.0f;                                                             // retrieve_optimized_depth :868-880
+    if (disp > 0.0f) { o = __fdiv_rn(bf, disp); if (o > P.max_depth) o = P.max_depth; }
+    out[idx] = o;
 }
 
 // ---------------------------------------------------------------------------------
