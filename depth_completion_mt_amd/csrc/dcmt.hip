@@ -68,7 +68,8 @@ struct dcmt_ctx {
     size_t slic_center_cap = 0;                 // centres per frame the two buffers above hold
     int label_group = 0;              // LC fast path, two columns per lane: labels side by side per wave (0 = by label size); env DCMT_LABEL_GROUP
     int label_pairs = -1;             // LC fast path: one wave per label pair (1), per label (0), by label size (-1); env DCMT_LABEL_PAIRS
-    int min_fused_batch = 12;         // smaller batches use the staged kernels (measured crossover: tools/batch_sweep.py); env DCMT_MIN_FUSED_BATCH
+    int min_fused_batch = 8;          // smaller batches use the staged kernels (measured crossover, tools/batch_sweep.py: 6 frames 49 k staged / 44 k streaming,
+                                      // 8 frames 51 k / 58 k, 12 frames 53 k / 84 k frames/s); env DCMT_MIN_FUSED_BATCH
 };
 
 namespace {
