@@ -14,7 +14,7 @@ data path; torch.distributed carries the barriers and the max-over-ranks of the 
 Prints ONE JSON line (rank 0).  value = frames/s over all ranks.
   roofline      whole cascade of one step on one GPU: algorithmic bytes (8 B/px: sparse f32 in + dense f32 out, intermediates
                 count zero) / mean GPU time per step, HIP events on the launch stream; .per_kernel = the library's own events
-                around k_pre_s / k_fp_s (dcmt_set_kernel_timing) in an extra untimed pass; .valu = the instruction-issue
+                around k_pre / k_fp_s (dcmt_set_kernel_timing) in an extra untimed pass; .valu = the instruction-issue
                 side (what actually binds both kernels), from the SQ counters of profiles/valu_latest.json; .traffic from the
                 PMC passes of profiles/traffic_latest.json (both written by tools/collect_profiles.sh on the builder's box).
   configs       (rank 0, N = 1) the other BASELINE configs, each with its own roofline: [1] batch = 1 streamed,
@@ -184,7 +184,7 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
         iters, st = c.last_fill_iters(Bl)
         out[key] = {"workload": f"{name} interpolate_with_superpixels, {cols}x{rows} f32 + int32 labels ({nl} labels), device-resident batch of {Bl}",
                     "value": Bl * 1e3 / ms, "unit": "frames/s", "converged": st == 0,
-                    "roofline": dict(hbm_roofline(Bl * rows * cols * 12, ms), per_kernel_ms={"label_stage": kt["front"], "k_pre_s": kt["k_pre_s"], "k_fp_s": kt["k_fp_s"]})}
+                    "roofline": dict(hbm_roofline(Bl * rows * cols * 12, ms), per_kernel_ms={"label_stage": kt["front"], "k_pre": kt["k_pre"], "k_fp_s": kt["k_fp_s"]})}
         c.close()
         del d, dl, o
     return out
@@ -376,12 +376,12 @@ def main():
         for _ in range(nk):
             step()
             t = ctx.last_kernel_times()
-            kt = [a + b / nk for a, b in zip(kt, (t["front"], t["k_pre_s"], t["k_fp_s"], t["behind"]))]
+            kt = [a + b / nk for a, b in zip(kt, (t["front"], t["k_pre"], t["k_fp_s"], t["behind"]))]
         ctx.set_kernel_timing(False)
         roof = hbm_roofline(B * BYTES_PER_FRAME, gpu_ms_per_step)
-        roof["kernel"] = ("whole cascade per step = k_pre_s + k_fp_s (+ 3 redo launches that return at once), HIP events around the K timed steps "
+        roof["kernel"] = ("whole cascade per step = k_pre_p + k_fp_s (+ 3 redo launches that return at once), HIP events around the K timed steps "
                           "on the launch stream; per_kernel: the library's own events (dcmt_set_kernel_timing) in 5 extra steps; rocprofv3 averages in profiles/")
-        roof["per_kernel"] = {"k_pre_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
+        roof["per_kernel"] = {"k_pre": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
                               "k_fp_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="reads X6, writes the dense frame"),
                               "redo_launches_ms": kt[3]}
         tr = load_profile_json("traffic_latest.json")

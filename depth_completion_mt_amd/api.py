@@ -244,7 +244,7 @@ class Context:
         st = L.lib().dcmt_last_kernel_times(self._h, ms)
         if st != L.OK:
             raise DcmtError(st, "dcmt_last_kernel_times")
-        return {"front": ms[0], "k_pre_s": ms[1], "k_fp_s": ms[2], "behind": ms[3]}
+        return {"front": ms[0], "k_pre": ms[1], "k_fp_s": ms[2], "behind": ms[3]}
 
     def last_holes_after_extend(self, n: int):
         out = (ctypes.c_int * n)()
