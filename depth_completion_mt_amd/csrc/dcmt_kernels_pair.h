@@ -1,8 +1,10 @@
 // dcmt_kernels_pair.h -- k_pre_p: H2..H6 (k_pre_s of dcmt_kernels_fused.h) with TWO adjacent columns per lane.
 //
 // A wave64 owns 128 columns over the full image height: lane l holds columns c0 + 2l ("E") and c0 + 2l + 1 ("O") in two
-// registers and streams down the rows like k_pre_s.  What that buys (both kernels are bound by VALU issue, and every
-// max / min / select / DPP instruction costs the same ~4.4 cycles whatever it does):
+// registers and streams down the rows like k_pre_s.  What that buys (every max / min / select / DPP instruction costs the
+// same ~4.4 issue cycles whatever it does; with 313 M of them per 1024 frames k_pre_s sat at the edge between issue- and
+// memory-bound, this kernel needs 218 M and is bound by memory alone, which is what small batches and the label-masked
+// variant's H5 + H6 feel):
 //   * half of every horizontal window is already in the lane.  With m = max(E, O):
 //         3-window   E: max(O[l-1], m)            O: max(E[l+1], m)                      3 instructions per column pair (4)
 //         r -> r+1   E: max(W_O[l-1], W_O[l])     O: max(W_E[l+1], W_E[l])   (r >= 1)    2 instructions per column pair (4)
@@ -13,7 +15,7 @@
 //   * rows arrive as 8 bytes per lane (buffer_load_dwordx2, 6 rows ahead) and leave as one buffer_store_dwordx2: 512-byte
 //     row segments.  (An LDS-DMA ring like k_pre_s's was measured too: 6 % slower here -- the plain loads already move whole
 //     lines, and the ring ties the loads' waits to the stores.)
-// Per row step: ~62 issue-bound instructions for 108 columns (k_pre_s: 41.5 for 44).
+// Per row step: 64 instructions (56 of the 4.4-cycle class) for 108 columns (k_pre_s: 41.5 for 44).
 //
 // Requires an even number of columns (a lane's two columns are both inside the image or both outside, its 8-byte accesses
 // are aligned).  Other shapes run k_pre_s.
@@ -228,7 +230,7 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             }
             // both columns leave in one 8-byte store once either has had its first valid row (what lands above a column's own first
             // valid row is never read in table mode and rewritten by the epilogue otherwise); the store itself is issued on every
-            // step by every lane (the DMA waits count on it), aimed past the buffer when there is nothing to write
+            // step by every lane, aimed past the buffer when there is nothing to write (no branch in the row step)
             // (a band below the first one stores all its rows: the rows between a column's first valid row in an upper band and its
             // first one here are real holes that the reader looks at)
             st2(ob, (inrows && outlane && (band > 0 || m >= min(tie, tio))) ? oc : kDropOffset, inrows ? m : 0, cols, x5);
