@@ -187,6 +187,16 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
                     "roofline": dict(hbm_roofline(Bl * rows * cols * 12, ms), per_kernel_ms={"label_stage": kt["front"], "k_pre": kt["k_pre"], "k_fp_s": kt["k_fp_s"]})}
         c.close()
         del d, dl, o
+        # the same at 1024 frames per step (the batch the headline is quoted on: 256 frames are 1.4 rounds of k_fp_s waves)
+        Bb = 1024
+        d = torch.from_numpy(synth.synth_batch(8, rows, cols, 0)).cuda().repeat(Bb // 8, 1, 1).contiguous()
+        dl = torch.from_numpy(lab).cuda()[None].repeat(Bb, 1, 1).contiguous()
+        o = torch.empty_like(d)
+        c = Context(local_rank, rows, cols, Bb)
+        ms = timed(torch, lambda: c.complete_dev(d, o, params, d_labels=dl, n_labels=nl, stream=stream.cuda_stream), 5, stream)
+        out[key]["at_batch_1024"] = {"value": Bb * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(Bb * rows * cols * 12, ms)}
+        c.close()
+        del d, dl, o
     return out
 
 

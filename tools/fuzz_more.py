@@ -1,0 +1,13 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+import test_gpu_fuzz as F
+bad = 0
+for seed in range(12, 132):
+    try:
+        F.test_fuzz_against_oracle(seed)
+    except AssertionError as e:
+        bad += 1
+        print("SEED", seed, str(e)[:300])
+print("done, failures:", bad)
