@@ -975,7 +975,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     const unsigned sbb = 4u * (unsigned)gxbc + (unsigned)V * rowb;
     const unsigned fla = 4u * (unsigned)gxac + (unsigned)max(tia, V) * rowb, cea = 4u * (unsigned)gxac + (unsigned)max(bia, V) * rowb;
     const unsigned flb = 4u * (unsigned)gxbc + (unsigned)max(tib, V) * rowb, ceb = 4u * (unsigned)gxbc + (unsigned)max(bib, V) * rowb;
-    auto clamp3 = [](unsigned a, unsigned lo, unsigned hi) -> unsigned { return min(max(a, lo), hi); };     // v_med3_u32
+    // (lo <= hi: the median of the three is the clamp.  hipcc has no builtin for the integer med3 and does not form it from min(max()).)
+    auto clamp3 = [](unsigned a, unsigned lo, unsigned hi) -> unsigned { unsigned r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi)); return r; };
     auto ld_a = [&](int row) -> float { return sf.ld_at(clamp3(sba + (unsigned)row * rowb, fla, cea)); };   // row relative to V, already clamped to [0, rows)
     auto ld_b = [&](int row) -> float { return sf.ld_at(clamp3(sbb + (unsigned)row * rowb, flb, ceb)); };
     const bool own = gxa >= 0 && gxa < cols && lane >= PostS::H && lane < 64 - PostS::H;   // columns this wave accounts for
