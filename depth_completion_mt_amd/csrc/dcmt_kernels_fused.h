@@ -993,30 +993,35 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
 
     constexpr float NEG = -FLT_MAX;
-    float PFA[16], PFB[16], W2A[16], W4A[16], W8A[16], W2B[16], W4B[16], W8B[16], DL[8];
+    // Warm start: with V > 0 the rows above V equal row V (a hole-free row of the constant zone), so the first 16 steps -- which
+    // would feed row V sixteen times (stream rows 0..15 = image rows V-15..V, clamped) -- are replaced by the state they leave
+    // behind: every window maximum and every delay-line slot holds row V.
+    const bool warm = V > 0;
+    const float xa0 = warm ? ld_a(0) : NEG, xb0 = warm ? ld_b(0) : NEG;
+    float PFA[16], PFB[16], W2A[16], W6A[16], W2B[16], W6B[16], DL[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { PFA[q] = PFB[q] = 0.f; W2A[q] = W4A[q] = W8A[q] = W2B[q] = W4B[q] = W8B[q] = NEG; }
+    for (int q = 0; q < 16; ++q) { PFA[q] = PFB[q] = 0.f; W2A[q] = W6A[q] = xa0; W2B[q] = W6B[q] = xb0; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) DL[q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { dl_c[q][lane] = NEG; dl_a[q][lane] = NEG; dl_b[q][lb] = NEG; }
+    for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; dl_b[q][lb] = xb0; }
 #ifndef DCMT_FP_PFD
 #define DCMT_FP_PFD 6
 #endif
     constexpr int PFD = DCMT_FP_PFD;         // rows of load lookahead
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
-        const int row = min(max(q - 15, 0), rows - 1);
+        const int row = min(max(q + (warm ? 16 : 0) - 15, 0), rows - 1);       // step 0's (or step 16's) first rows
         PFA[q] = ld_a(row); PFB[q] = ld_b(row);
     }
-    float vpa = NEG, vpb = NEG, x7_prev = 0.f;
+    float vpa = xa0, vpb = xb0, x7_prev = warm ? xa0 : 0.f;
     int before = 0, after = 0;
     // Software skew: the two ds_bpermutes and the two delay-line reads issued in step t are consumed
     // in step t + 1, so their LDS round trips overlap the next step's arithmetic instead of
     // stalling the wave (s_waitcnt) three times per step.
-    float pend_m = NEG, pend_v = NEG, pend_slo = NEG, pend_phi = NEG;   // of stream row t - 1
+    float pend_m = NEG, pend_v = xa0, pend_slo = NEG, pend_phi = NEG;   // of stream row t - 1
     unsigned long long pend_hm = 0;                                      // its hole mask (wave-uniform, lives in SGPRs)
-    float nxt_c = NEG, nxt_a = NEG, nxt_b = NEG;                         // delay-line values for the next step
+    float nxt_c = xa0, nxt_a = xa0, nxt_b = xb0;                         // delay-line values for the next step
 
     // the fill front end of step t: returns X7 of image row t - 31 for every lane
     auto fill_step = [&](auto P_, int t) -> float {
@@ -1042,25 +1047,26 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         if (o >= rows) { asm volatile("" ::); x7 = x7_prev; }       // rows below the image replicate the last row (median border); the
                                                                     // empty asm keeps this a scalar branch (last 7 steps only) instead of a select per step
         x7_prev = x7;
-        // vertical 31-max, both registers (see k_fill_s)
+        // vertical 31-max, both registers, in FOUR instructions per register (three-input maxima cost what two-input ones do):
+        //   w2 = rows t-1..t;  w6 = max3(w2, w2[t-2], w2[t-4]) = rows t-5..t;  w18 = max3(w6, w6[t-6], w6[t-12]) = rows t-17..t;
+        //   w31 = max(w18, w18[t-13]) = rows t-30..t          (k_fill_s: doubling 2, 4, 8, 16, +15 in five)
         const float w2a = fmax2(xa, vpa), w2b = fmax2(xb, vpb);
         vpa = xa; vpb = xb;
         W2A[p] = w2a; W2B[p] = w2b;
-        const float w4a = fmax2(w2a, W2A[(p + 14) & 15]), w4b = fmax2(w2b, W2B[(p + 14) & 15]);
-        W4A[p] = w4a; W4B[p] = w4b;
-        const float w8a = fmax2(w4a, W4A[(p + 12) & 15]), w8b = fmax2(w4b, W4B[(p + 12) & 15]);
-        W8A[p] = w8a; W8B[p] = w8b;
-        const float w16a = fmax2(w8a, W8A[(p + 8) & 15]), w16b = fmax2(w8b, W8B[(p + 8) & 15]);
-        // LDS delay lines: slot (t & 15) is written now; slot ((t + 1) & 15), written 15 steps ago, was
-        // fetched during the previous step, and slot ((t + 2) & 15) is fetched now for the next one
-        const float v = nxt_c, w16a_old = nxt_a, w16b_old = nxt_b;  // stream row t - 15
+        const float w6a = fmax3(w2a, W2A[(p + 14) & 15], W2A[(p + 12) & 15]), w6b = fmax3(w2b, W2B[(p + 14) & 15], W2B[(p + 12) & 15]);
+        W6A[p] = w6a; W6B[p] = w6b;
+        const float w18a = fmax3(w6a, W6A[(p + 10) & 15], W6A[(p + 4) & 15]), w18b = fmax3(w6b, W6B[(p + 10) & 15], W6B[(p + 4) & 15]);
+        // LDS delay lines: slot (t & 15) is written now.  Centre values are delayed by 15 steps: slot ((t + 1) & 15), written 15
+        // steps ago, was fetched during the previous step, and slot ((t + 2) & 15) is fetched now for the next one.  The 18-row
+        // maxima are delayed by 13: the slot fetched now for the next step is ((t + 1) - 13) & 15 = (t + 4) & 15.
+        const float v = nxt_c, w18a_old = nxt_a, w18b_old = nxt_b;  // stream row t - 15; maxima of step t - 13
         nxt_c = dl_c[(p + 2) & 15][lane];
-        nxt_a = dl_a[(p + 2) & 15][lane];
-        nxt_b = dl_b[(p + 2) & 15][lb];
+        nxt_a = dl_a[(p + 4) & 15][lane];
+        nxt_b = dl_b[(p + 4) & 15][lb];
         dl_c[p][lane] = xa;
-        dl_a[p][lane] = w16a;
-        dl_b[p][lb] = w16b;
-        const float w31a = fmax2(w16a, w16a_old), w31b = fmax2(w16b, w16b_old);
+        dl_a[p][lane] = w18a;
+        dl_b[p][lb] = w18b;
+        const float w31a = fmax2(w18a, w18a_old), w31b = fmax2(w18b, w18b_old);
         // horizontal 31-max: scans now, the cross-row fetches land during the next step.  The fill only
         // replaces holes (x < thr), so a row in which none of this wave's 64 columns is a hole needs no
         // horizontal maximum at all (wave-uniform skip; the vertical state above is always kept current).
@@ -1078,8 +1084,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         return x7;
     };
 
-    // steps 0..31: fill only (X7 row 0 appears at t = 31)
-    for (int t0 = 0; t0 < FpS::LAG; t0 += 16) {
+    // steps 0..31 (16..31 after a warm start): fill only (X7 row 0 appears at t = 31)
+    for (int t0 = warm ? 16 : 0; t0 < FpS::LAG; t0 += 16) {
         static_for<0, 16>([&](auto P_) {
             constexpr int p = decltype(P_)::value;
             DL[p & 7] = fill_step(P_, t0 + p);
