@@ -210,11 +210,23 @@ __device__ __forceinline__ float grey_dx(const uint8_t* g, int r, int c, int row
 // (e1 = e0 + 1, also across the end of a row, which the reference's at<>() reads too), so the six are four distinct bytes:
 // g[e0-1], g[e0], g[e1], g[e1+1].  All arithmetic as in the oracle: one rounding per operation, IEEE divisions where the
 // reference divides (initial disparity, every sweep's step, final depth).
+// LDS_ROW: the workgroup first stages the whole right-image row (and the first pixel of the next one) in LDS: a sweep's
+// bytes then come from ds_read_u8 instead of four byte gathers through the texture path, which is what bound the first
+// version (1.42 ms per 256 pairs of 1242x375 with ~250 VALU instructions per pixel: the CU's address unit takes a 64-lane byte
+// load at a few lanes per cycle).  Dynamic LDS: cols + 1 bytes.
+template <bool LDS_ROW>
 __global__ __launch_bounds__(256)
 void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                      float* __restrict__ out, int rows, int cols, int batch, StereoP P)
 {
+    extern __shared__ uint8_t s_row[];
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if constexpr (LDS_ROW) {
+        const uint8_t* g = right + (size_t)blockIdx.z * rows * cols + (size_t)i * cols;
+        const int n = i + 1 < rows ? cols + 1 : cols;
+        for (int k = threadIdx.x; k < n; k += 256) s_row[k] = g[k];
+        __syncthreads();
+    }
     if (j >= cols) return;
     const size_t fe = (size_t)rows * cols, idx = (size_t)blockIdx.z * fe + (size_t)i * cols + j;
     const int fei = (int)fe;                                                    // a frame has < 2^29 pixels (dcmt_create)
@@ -231,11 +243,12 @@ void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict_
         const int e0 = i * cols + c0, e1 = e0 + 1;                              // p00, p01 (p01 may be the next row's first pixel)
         if (e1 >= fei) continue;
         const bool wrap = c0 + 1 == cols;                                       // p01 = (i + 1, 0)
-        const float g0 = (float)gr[e0], g1 = (float)gr[e1];
+        auto px = [&](int e) -> float { if constexpr (LDS_ROW) return (float)s_row[e - i * cols]; else return (float)gr[e]; };
+        const float g0 = px(e0), g1 = px(e1);
         // central differences (calculateMeasuementDerivatives :715-745): 0 on the image border
         float dx0 = 0.0f, dx1 = 0.0f;
-        if (row_in && c0 >= 1 && c0 < cols - 1) dx0 = __fsub_rn(__fmul_rn(0.5f, g1), __fmul_rn(0.5f, (float)gr[e0 - 1]));
-        if (!wrap && row_in && c0 + 1 < cols - 1) dx1 = __fsub_rn(__fmul_rn(0.5f, (float)gr[e1 + 1]), __fmul_rn(0.5f, g0));   // (a wrapped p01 sits in column 0: border, 0)
+        if (row_in && c0 >= 1 && c0 < cols - 1) dx0 = __fsub_rn(__fmul_rn(0.5f, g1), __fmul_rn(0.5f, px(e0 - 1)));
+        if (!wrap && row_in && c0 + 1 < cols - 1) dx1 = __fsub_rn(__fmul_rn(0.5f, px(e1 + 1)), __fmul_rn(0.5f, g0));   // (a wrapped p01 sits in column 0: border, 0)
         const float dc = __fsub_rn(c, (float)c0), dc1 = __fsub_rn(1.0f, dc);
         const float value = __fadd_rn(__fmul_rn(g0, dc1), __fmul_rn(g1, dc));
         const float dx = __fadd_rn(__fmul_rn(dx0, dc1), __fmul_rn(dx1, dc));
