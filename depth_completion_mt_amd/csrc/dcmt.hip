@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -210,7 +211,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     ctx->last_batch = batch;
     ctx->last_apps_launched = 0;
     ctx->last_has_loop = 0;
-    DCMT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(int) * (size_t)batch * kCntStride, st));
+    // (the hole counters are cleared by the first kernel of the chain: clear_frame_counters)
     auto stamp = [&](int i) { if (ctx->timing && ctx->tev[i]) (void)hipEventRecord(ctx->tev[i], st); };
     stamp(1);
     const size_t fe = (size_t)rows * cols;
@@ -229,7 +230,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         int* cnt = ctx->counters + (size_t)f0 * kCntStride;
         const float* cf = coef ? coef + 2 * (size_t)f0 : nullptr;
         // table mode: only the k_fp_s path reads X6 through the per-column table (the probes and the unfused kernels get a fully written X6)
-        int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tb + (size_t)f0 * 2 * cols : nullptr;
+        int bands = 1;                      // row bands of k_pre_p = table slots per frame
+        int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tb : nullptr;   // chunks follow each other in the stream: each may use the whole table
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
             // LDS-DMA rows need 16-byte aligned sources: cols % 4 == 0 and a 16-byte aligned base
@@ -237,37 +239,34 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr;
 #define DCMT_PRE(KIND, WIDE) { using G = PreS<KIND, WIDE>; const int strips = (cols + G::VW - 1) / G::VW; \
                 if (d_x4) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, true, false>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt); \
                 else if (src16) hipLaunchKernelGGL((k_pre_s<KIND, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src16, o6, \
-                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc); \
+                                             rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc, cnt); \
                 else if (cf) hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false, true>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc, cnt); \
                 else hipLaunchKernelGGL((k_pre_s<KIND, WIDE, false, false>), wave_grid(strips, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); }
+                                        rows, cols, strips, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt); }
             // two columns per lane (k_pre_p) wherever a lane's 8-byte accesses are aligned: even width, 8-byte aligned frames
             const bool pair = ctx->pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)(src16 ? (const void*)src16 : (const void*)src) % (src16 ? 4 : 8) == 0) &&
                               ((uintptr_t)o6 % 8 == 0);
-            // row bands: full-height strips of a small batch leave most wave slots empty; bands need the (ti, bi) table
-            int bands = 1;
+            // row bands: full-height strips of a small batch leave most wave slots empty; bands need the (ti, bi) table (one slot per band)
             if (pair && tc) {
                 const int pstr = (cols + PreP<K0_AS_COMPILED, false>::VW - 1) / PreP<K0_AS_COMPILED, false>::VW;
                 bands = ctx->bands > 0 ? ctx->bands : ((long long)nb * pstr >= 2560 ? 1 : (int)((2560 + (long long)nb * pstr - 1) / ((long long)nb * pstr)));
                 if (bands > rows / 32) bands = rows / 32 > 0 ? rows / 32 : 1;
-                if (bands > 8) bands = 8;
+                if (bands > kMaxBands) bands = kMaxBands;
             }
 #define DCMT_PREP(KIND) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
-                if (bands > 1) hipLaunchKernelGGL(k_tb_init, dim3(64), dim3(256), 0, ps, tc, cols, nb); \
                 if (d_x4) { const int strips = (cols + G4::VW - 1) / G4::VW; \
                     hipLaunchKernelGGL((k_pre_p<KIND, true, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); } \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt); } \
                 else { const int strips = (cols + G0::VW - 1) / G0::VW; \
                     if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src16, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc); \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc, cnt); \
                     else if (cf) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc); \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc, cnt); \
                     else hipLaunchKernelGGL((k_pre_p<KIND, false, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc); } \
-                if (bands > 1) hipLaunchKernelGGL(k_tb_fix, dim3(64), dim3(256), 0, ps, tc, o6, rows, cols, nb); }
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt); } }
             if (pair) {
                 if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED) else DCMT_PREP(K0_DIAMOND)
             } else {
@@ -288,8 +287,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
             // k_fp_s deals (frame, strip) pairs to waves in one flat sequence (per XCD with the XCD map): no half-empty workgroups
             const dim3 fpg = wave_grid(pstrips, nb, xm);
-            if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc);
-            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc);
+            if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
             DCMT_HIP(ctx, hipGetLastError());
             stamp(3);
             ctx->last_has_loop = 1;
@@ -302,11 +301,11 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     for (int f = 0; f < batch; ++f) any |= ctx->h_counters[(size_t)f * kCntStride + 1] > 0;
                     if (!any) { if (p->verbose) for (int f = 0; f < batch; ++f) std::printf("0\n"); continue; }
                 }
-                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1, (const int*)tc);
+                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1, (const int*)tc, bands);
                 int apps = 0;
                 const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
                     hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                                       fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr);
+                                       fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr, 1);
                 }, &apps);
                 if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
                 if (lrc != DCMT_OK) rc = lrc;
@@ -320,7 +319,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             continue;
         }
         hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
-                           fstrips, nb, xm, p->valid_thresh, 0, 0, (const int*)nullptr);
+                           fstrips, nb, xm, p->valid_thresh, 0, 0, (const int*)nullptr, 1);
         DCMT_HIP(ctx, hipGetLastError());
         if (stop == DCMT_STAGE_FILL31) continue;
 
@@ -328,7 +327,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         int apps = 0;
         const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
             hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                               fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr);
+                               fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr, 1);
         }, &apps);
         if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
         if (lrc != DCMT_OK) rc = lrc;
@@ -672,7 +671,10 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + FTH_FEW - 1) / FTH_FEW) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->tb, sizeof(int) * 2 * (size_t)max_cols * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    // (first, last) table: one slot per frame and row band.  Bands are only chosen while frames x strips x bands stays near one
+    // round of waves (run_chain_fused), so frames x bands <= max_batch + 2560; an explicit DCMT_BANDS may go up to kMaxBands each.
+    const size_t tb_slots = ctx->bands > 0 ? (size_t)max_batch * kMaxBands : std::min<size_t>((size_t)max_batch * kMaxBands, (size_t)max_batch + 2560);
+    if (hipMalloc((void**)&ctx->tb, sizeof(int) * 2 * (size_t)max_cols * tb_slots) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->h_counters, sizeof(int) * (size_t)kCntStride * max_batch, hipHostMallocDefault) != hipSuccess)

@@ -132,6 +132,30 @@ __device__ __forceinline__ bool wave_strip(int b, int wave, int strips, int batc
     return true;
 }
 
+// The hole counters of a frame (k_fp_s / k_fill_s add to them later in the stream) start every call at zero: the first
+// kernel of the chain clears them, one wave per frame -- a memset in front would be one more dependent operation in the
+// stream (2 us + a 6 us gap, measured).  counters == nullptr: the caller has cleared them.
+__device__ __forceinline__ void clear_frame_counters(int* counters, int f, bool first_wave_of_frame, int lane)
+{
+    if (counters && first_wave_of_frame)
+        for (int i = lane; i < kCntStride; i += 64) counters[(size_t)f * kCntStride + i] = 0;
+}
+
+// (first, last) valid row of column c of frame f from the table k_pre_s / k_pre_p leave in table mode.  A launch with row
+// bands leaves one slot per band -- [f][band][0][col] = first valid row of the band's rows or INT_MAX, [f][band][1][col] =
+// last valid row or -1 -- and the reader combines them; a column no band found a valid row in is 100 everywhere
+// (LO :110, :125-127): both rows point at the last row, where the last band has put the 100.  Unbanded launches have
+// done that translation themselves.
+__device__ __forceinline__ void table_rows(const int* tb, int f, int cols, int bands, int rows, int c, int& first, int& last)
+{
+    const int* tt = tb + (size_t)f * bands * 2 * cols + c;
+    first = tt[0]; last = tt[cols];
+    if (bands > 1) {
+        for (int b = 1; b < bands; ++b) { first = min(first, tt[(size_t)b * 2 * cols]); last = max(last, tt[(size_t)b * 2 * cols + cols]); }
+        if (last < 0) first = last = rows - 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // RowRing: wave-private LDS ring filled by LDS-DMA.  One global_load_lds_dwordx4 moves a 4-row
 // x 64-column block (64 lanes x 16 B, the widest access) for the wave's strip straight into
@@ -207,7 +231,7 @@ template <int K0KIND, bool WIDE, bool START4 = false, bool U16 = false, bool NOR
 __global__ __launch_bounds__(256)
 void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
-             int* __restrict__ tb)
+             int* __restrict__ tb, int* __restrict__ counters)
 {
     static_assert(!(U16 && (WIDE || START4)), "the uint16 ingest uses the plain row loads");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
@@ -223,6 +247,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);             // wave-uniform: keep it scalar
     int f, strip;
     if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;   // whole waves leave; no barrier is used below
+    clear_frame_counters(counters, f, strip == 0, lane);
     const int gx = strip * G::VW - G::HL + lane;
     const bool incol = gx >= 0 && gx < cols;
     const bool outlane = incol && lane >= G::HL && lane < G::HL + G::VW;
@@ -831,7 +856,7 @@ __device__ __forceinline__ void row_scans3(float a, float b, float& pa, float& s
 
 __global__ __launch_bounds__(256)
 void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tb)
+              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tb, int tbands)
 {
     const int lane = threadIdx.x & 63;
     int f, sg;
@@ -850,7 +875,8 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     const int a_lo = ((lane - FillS::R) & 63) * 4, a_hi = ((lane + FillS::R) & 63) * 4;   // bpermute byte addresses
     // tb: `in` is an X6 whose extension zones were never written (k_pre_s / k_pre_p, table mode): the rows above a column's first
     // valid row equal that row, the rows below its last valid row equal that one, so the row index is clamped per lane
-    const int tl = tb ? tb[(size_t)f * 2 * cols + gxc] : 0, bl = tb ? tb[(size_t)f * 2 * cols + cols + gxc] : rows - 1;
+    int tl = 0, bl = rows - 1;
+    if (tb) table_rows(tb, f, cols, tbands, rows, gxc, tl, bl);
 
     // rolling rows, slot = row & 15 (16-step unroll keeps every index static)
     float PF[16], XC[16], W2[16], W4[16], W8[16], W16[16];
@@ -935,7 +961,8 @@ struct FpS {
 template <bool BLUR>
 __global__ __launch_bounds__(256)
 void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
-            int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb)
+            int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb,
+            int tbands)
 {
     // per wave, three 15-step delay lines: centre values, A's 16-row maxima (64 lanes each), B's 16-row
     // maxima (only its 30 halo lanes: packed to 32) -- 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
@@ -963,8 +990,8 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     // 0 .. V-1 as well -- on velodyne-like frames (upper third empty) that is a quarter of the row steps of this kernel.
     int tia = 0, tib = 0, bia = rows_all - 1, bib = rows_all - 1, V = 0;
     if (tb) {
-        const int* tt = tb + (size_t)f * 2 * cols;
-        tia = tt[gxac]; tib = tt[gxbc]; bia = tt[cols + gxac]; bib = tt[cols + gxbc];
+        table_rows(tb, f, cols, tbands, rows_all, gxac, tia, bia);
+        table_rows(tb, f, cols, tbands, rows_all, gxbc, tib, bib);
         V = __builtin_amdgcn_readfirstlane(max(wave_min_i(min(tia, tib)) - 8, 0));   // wave-uniform: keep the row arithmetic scalar
     }
     const int rows = rows_all - V;                                   // rows of the frame as this wave sees it (>= 9)

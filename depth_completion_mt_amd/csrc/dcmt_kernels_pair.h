@@ -68,16 +68,18 @@ struct PreP {
     static constexpr int LAT = 9;
 };
 
+constexpr int kMaxBands = 8;                 // row bands per strip (table slots per frame)
+
 // Row bands: with few frames a grid of full-height strips cannot fill the GPU (128 frames x 12 strips = 1536 waves for 4096
 // slots), so a strip may be cut into `bands` row ranges, one wave each.  A band starts its stream 18 rows above its first row
 // with cold rings (exactly like the start below the leading empty rows) and accounts for the x5 rows [r0, r1) only; the
-// per-column (ti, bi) of the bands are combined with atomicMin / atomicMax in the table (which the host initialises), which
-// is why bands need table mode.
+// per-column (ti, bi) of the bands go to one table slot per band, which the reader combines (table_rows), which is why
+// bands need table mode.
 template <int K0KIND, bool START4 = false, bool U16 = false, bool NORM = false>
 __global__ __launch_bounds__(256)
 void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips, int bands,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
-             int* __restrict__ tb)
+             int* __restrict__ tb, int* __restrict__ counters)
 {
     static_assert(!(U16 && START4), "the uint16 ingest is the first kernel of the path");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
@@ -89,6 +91,7 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     int f, unit;
     if (!wave_strip(blockIdx.x, wave, strips * bands, batch, xcd_map, f, unit)) return;   // whole waves leave; no barrier is used below
     const int strip = unit / bands, band = unit - strip * bands;
+    clear_frame_counters(counters, f, unit == 0, lane);
     const int gx0 = strip * G::VW - G::HL;
     const int gx = gx0 + 2 * lane;                                   // column of E; O = gx + 1
     const bool incol = gx >= 0 && gx < cols;                         // cols is even and gx is even: E and O are inside or outside together
@@ -238,22 +241,20 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     }
     if (tb) {
         // table mode: [f][0][col] = first valid row (rows - 1 for an empty column, whose last row gets the 100 of LO :110, :125-127),
-        // [f][1][col] = last valid row (same).  Bands combine by min / max; the host initialises the table.
-        int* tt = tb + (size_t)f * 2 * cols, *bt = tt + cols;
+        // [f][1][col] = last valid row (same).  With bands every band leaves its own slot [f][band][.][col] as found (INT_MAX / -1
+        // for none) and the reader combines them (table_rows); the last band puts the 100 into the last row of every column IT found
+        // nothing in -- a row the reader only looks at when no band found anything (otherwise it lies below the column's last valid row).
+        int* tt = tb + ((size_t)f * bands + band) * 2 * cols, *bt = tt + cols;
         if (outlane) {
-            if (bands == 1) {
-                const bool ee = bie < 0, eo = bio < 0;
-                if (ee | eo) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ee) ob.st_at(oc + 4u * (unsigned)((rows - 1) * cols), 100.0f);
-                    if (eo) ob.st_at(oc + 4u + 4u * (unsigned)((rows - 1) * cols), 100.0f);
-                }
-                *reinterpret_cast<int2*>(tt + gx) = make_int2(ee ? rows - 1 : tie, eo ? rows - 1 : tio);
-                *reinterpret_cast<int2*>(bt + gx) = make_int2(ee ? rows - 1 : bie, eo ? rows - 1 : bio);
-            } else {
-                if (bie >= 0) { atomicMin(tt + gx, tie); atomicMax(bt + gx, bie); }
-                if (bio >= 0) { atomicMin(tt + gx + 1, tio); atomicMax(bt + gx + 1, bio); }
+            const bool ee = bie < 0, eo = bio < 0;
+            if ((ee | eo) && band == bands - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (ee) ob.st_at(oc + 4u * (unsigned)((rows - 1) * cols), 100.0f);
+                if (eo) ob.st_at(oc + 4u + 4u * (unsigned)((rows - 1) * cols), 100.0f);
             }
+            const bool tr = bands == 1;                                  // unbanded: the translation of an empty column is done here
+            *reinterpret_cast<int2*>(tt + gx) = make_int2(ee && tr ? rows - 1 : tie, eo && tr ? rows - 1 : tio);
+            *reinterpret_cast<int2*>(bt + gx) = make_int2(ee && tr ? rows - 1 : bie, eo && tr ? rows - 1 : bio);
         }
         return;
     }
@@ -273,28 +274,6 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     };
     extend(oc, tie, bie);
     extend(oc + 4u, tio, bio);
-}
-
-// Behind a banded k_pre_p: a column no band found a valid row in still holds the table's initial values.  It is 100
-// everywhere (LO :110, :125-127): point both entries at the last row and put the 100 there.
-__global__ void k_tb_fix(int* __restrict__ tb, float* __restrict__ x6, int rows, int cols, int batch)
-{
-    const size_t n = (size_t)batch * cols;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t f = i / cols, c = i - f * cols;
-        int* tt = tb + f * 2 * cols;
-        if (tt[cols + c] < 0) {
-            tt[c] = rows - 1; tt[cols + c] = rows - 1;
-            x6[(f * rows + (rows - 1)) * cols + c] = 100.0f;
-        }
-    }
-}
-// table initialisation for banded launches: first rows = INT_MAX, last rows = -1
-__global__ void k_tb_init(int* __restrict__ tb, int cols, int batch)
-{
-    const size_t n = (size_t)batch * 2 * cols;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        tb[i] = ((i / cols) & 1) ? -1 : 0x7fffffff;
 }
 
 }  // namespace dcmt
