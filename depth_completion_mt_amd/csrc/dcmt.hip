@@ -62,7 +62,7 @@ struct dcmt_ctx {
     int* bb_max = nullptr;
     size_t bb_ints = 0;
     // N3 (SLIC) scratch, allocated by the first dcmt_slic_labels_dev call
-    int* slic_cells = nullptr;                  // [max_batch][cells]: centres per cell, then [max_batch][cells][kSlicCellCap] their indices, then [max_batch] overflow flags
+    int* slic_cells = nullptr;                  // two cell sets: counts [batch][cells] + overflow flags [batch] each, then the index lists [batch][cells][kSlicCellCap] each
     size_t slic_cell_cap = 0;                   // cells per frame that buffer holds
     double* slic_centers[2] = {nullptr, nullptr};
     unsigned long long* slic_sums = nullptr;
@@ -820,14 +820,17 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     { const char* e = std::getenv("DCMT_SLIC_CELL_SCALE"); if (e && std::atoi(e) > 1) cell_px = step * std::atoi(e); }   // tests: crowded cells
     const int gx = (cols - 1) / cell_px + 1, gy = (rows - 1) / cell_px + 1;
     const size_t cells = (size_t)gx * gy;
+    // two cell sets (the assignment reads one while the next centres are binned into the other); per set [batch][cells] counts
+    // with the [batch] overflow flags right behind, and [batch][cells][kSlicCellCap] centre indices
     if (cells > ctx->slic_cell_cap) {
         (void)hipFree(ctx->slic_cells); ctx->slic_cells = nullptr; ctx->slic_cell_cap = 0;
-        DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_cells, sizeof(int) * ((size_t)ctx->max_batch * cells * (1 + kSlicCellCap) + ctx->max_batch)));
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->slic_cells, 2 * sizeof(int) * ((size_t)ctx->max_batch * cells * (1 + kSlicCellCap) + ctx->max_batch)));
         ctx->slic_cell_cap = cells;
     }
-    int* cell_cnt = ctx->slic_cells;                                      // [batch][cells] and, right behind, [batch] overflow flags:
-    int* overflow = cell_cnt + (size_t)batch * cells;                     // one memset clears both
-    int* cell_list = overflow + batch;
+    const size_t n_cnt = (size_t)batch * cells + batch;
+    int* set_cnt[2] = {ctx->slic_cells, ctx->slic_cells + n_cnt};
+    int* set_ovf[2] = {set_cnt[0] + (size_t)batch * cells, set_cnt[1] + (size_t)batch * cells};
+    int* set_list[2] = {ctx->slic_cells + 2 * n_cnt, ctx->slic_cells + 2 * n_cnt + (size_t)batch * cells * kSlicCellCap};
     if ((size_t)n > ctx->slic_center_cap) {
         (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]); (void)hipFree(ctx->slic_sums);
         ctx->slic_centers[0] = ctx->slic_centers[1] = nullptr; ctx->slic_sums = nullptr; ctx->slic_center_cap = 0;
@@ -838,16 +841,19 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
         ctx->slic_center_cap = (size_t)n;
     }
     DCMT_HIP(ctx, hipMemsetAsync(d_labels, 0xFF, sizeof(int32_t) * px, st));                    // clusters = -1 (slic.cpp:24)
-    hipLaunchKernelGGL(k_slic_init, dim3((n + 63) / 64, batch), dim3(64), 0, st, d_lab, ctx->slic_centers[0], rows, cols, step, n);
+    DCMT_HIP(ctx, hipMemsetAsync(set_cnt[0], 0, sizeof(int) * 2 * n_cnt, st));                  // both cell sets' counts and flags
+    DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_sums, 0, sizeof(unsigned long long) * 6 * (size_t)n * batch, st));   // every iteration leaves them zeroed
+    hipLaunchKernelGGL(k_slic_init, dim3((n + 63) / 64, batch), dim3(64), 0, st, d_lab, ctx->slic_centers[0], rows, cols, step, n,
+                       set_cnt[0], set_list[0], set_ovf[0], cell_px, gx, gy);
+    const size_t nb_threads = std::max((size_t)n * batch, n_cnt);
     for (int it = 0; it < 10; ++it) {                                                           // NR_ITERATIONS (slic.h:20)
         double* cur = ctx->slic_centers[it & 1];
         double* nxt = ctx->slic_centers[(it + 1) & 1];
-        DCMT_HIP(ctx, hipMemsetAsync(cell_cnt, 0, sizeof(int) * ((size_t)batch * cells + batch), st));
-        DCMT_HIP(ctx, hipMemsetAsync(ctx->slic_sums, 0, sizeof(unsigned long long) * 6 * (size_t)n * batch, st));
-        hipLaunchKernelGGL(k_slic_bin, dim3((n + 63) / 64, batch), dim3(64), 0, st, cur, cell_cnt, cell_list, overflow, cell_px, n, gx, gy);
+        const int a = it & 1, b = a ^ 1;
         hipLaunchKernelGGL(k_slic_assign, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + kSlicTH - 1) / kSlicTH, batch), dim3(256), 0, st, d_lab, cur,
-                           cell_cnt, cell_list, overflow, d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
-        hipLaunchKernelGGL(k_slic_norm, dim3((n * batch + 255) / 256), dim3(256), 0, st, ctx->slic_sums, nxt, n * batch);
+                           set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
+        hipLaunchKernelGGL(k_slic_norm_bin, dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, st, ctx->slic_sums, nxt, n, batch,
+                           set_cnt[b], set_list[b], set_ovf[b], set_cnt[a], (int)n_cnt, cell_px, gx, gy);
         DCMT_HIP(ctx, hipGetLastError());
     }
     if (d_centers)       // ten iterations: the final centres are back in buffer 0

@@ -5,7 +5,6 @@
 // The reference walks the centres in index order and lets a pixel take a centre whose distance is STRICTLY smaller,
 // so the result per pixel is  argmin over (distance, centre index)  of the centres whose [c - step, c + step) window
 // contains it -- an order-free definition.  Per iteration:
-//   k_slic_bin      centres -> cells of step x step pixels (count + short index list per cell);
 //   k_slic_assign   one thread per pixel: the candidates are the centres of the 3 x 3 cells around it whose window
 //                   holds the pixel; the winner is found on the un-rooted distance, and only candidates within 4e-12
 //                   of the minimum (exact ties included) are decided with the reference's own f64 arithmetic
@@ -14,8 +13,9 @@
 //                   old centre;
 //                   the winners' L, a, b, x, y and a count are summed per centre as integers (exact, order-free), in
 //                   LDS per tile and flushed with global atomics;
-//   k_slic_norm     centre = sums / count in f64; a centre without pixels is dead from then on (in the
-//                   reference it turns NaN and its window loop `k < NaN` never runs again).
+//   k_slic_norm_bin centre = sums / count in f64; a centre without pixels is dead from then on (in the
+//                   reference it turns NaN and its window loop `k < NaN` never runs again); the new centres go into
+//                   cells of step x step pixels (count + short index list per cell) for the next assignment.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -23,6 +23,7 @@
 namespace dcmt {
 
 constexpr unsigned long long kSlicDead = 0x7ff8000000000000ull;     // bit pattern of a dead centre's x (a NaN)
+constexpr int kSlicCellCap = 4;                                     // centre indices a cell's list holds
 
 __device__ __forceinline__ double slic_dist(const double* c, int x, int y, const uint8_t* px, double nc, double ns)
 {
@@ -43,7 +44,21 @@ __device__ __forceinline__ void slic_grid(int c, int rows, int step, int& i, int
     j = step * (c % ny + 1);
 }
 
-__global__ void k_slic_init(const uint8_t* __restrict__ lab, double* __restrict__ centers, int rows, int cols, int step, int n)
+// a centre goes into the list of its cell (at most kSlicCellCap per cell; more: the frame's overflow flag)
+__device__ __forceinline__ void slic_bin_one(const double* C, int j, int f, int* cell_cnt, int* cell_list, int* overflow,
+                                             int cell_px, int gx, int gy)
+{
+    if (__builtin_bit_cast(unsigned long long, C[3]) == kSlicDead) return;
+    const int cx = min(max((int)(C[3] / (double)cell_px), 0), gx - 1), cy = min(max((int)(C[4] / (double)cell_px), 0), gy - 1);
+    const size_t cell = ((size_t)f * gy + cy) * gx + cx;
+    const int slot = atomicAdd(&cell_cnt[cell], 1);
+    if (slot < kSlicCellCap) cell_list[cell * kSlicCellCap + slot] = j;
+    else overflow[f] = 1;
+}
+
+// initial centres (slic.cpp:19-57), binned into the (zeroed) cell set the first assignment reads
+__global__ void k_slic_init(const uint8_t* __restrict__ lab, double* __restrict__ centers, int rows, int cols, int step, int n,
+                            int* __restrict__ cell_cnt, int* __restrict__ cell_list, int* __restrict__ overflow, int cell_px, int gx, int gy)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (c >= n) return;
@@ -62,6 +77,7 @@ __global__ void k_slic_init(const uint8_t* __restrict__ lab, double* __restrict_
     double* C = centers + ((size_t)f * n + c) * 5;
     const uint8_t* px = img + 3 * ((size_t)my * cols + mx);
     C[0] = px[0]; C[1] = px[1]; C[2] = px[2]; C[3] = mx; C[4] = my;
+    slic_bin_one(C, c, f, cell_cnt, cell_list, overflow, cell_px, gx, gy);
 }
 
 // the window of a centre: [k0, k1) x [l0, l1), clipped to the image; false if dead or empty
@@ -77,7 +93,7 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 
 // ---- pixel-major assignment -------------------------------------------------------------------------------------
 // Centres are binned into cells of cell_px x cell_px pixels, cell_px = step (any cell_px >= step is correct: tests use
-// larger cells to force list overflows) (k_slic_bin: per cell a count and up to kSlicCellCap indices);
+// larger cells to force list overflows) (slic_bin_one: per cell a count and up to kSlicCellCap indices);
 // a centre whose window [c - step, c + step) contains pixel x has floor(c / step) within one cell of floor(x / step),
 // so every pixel looks at the 3 x 3 cells around its own.  If any cell of a frame overflows its list, the frame's
 // pixels walk all centres instead (correct, slow, never seen on SLIC-like data).
@@ -88,156 +104,258 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // smallest q is below every other by more than a factor 1 - 1e-12 the reference's comparison has the same winner.
 // Only candidates inside that band (exact ties included) are evaluated with slic_dist itself and compared as
 // (distance, centre index), which is the reference's rule.
-constexpr int kSlicCellCap = 4;
 
-__global__ void k_slic_bin(const double* __restrict__ centers, int* __restrict__ cell_cnt, int* __restrict__ cell_list,
-                           int* __restrict__ overflow, int cell_px, int n, int gx, int gy)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (j >= n) return;
-    const double* C = centers + ((size_t)f * n + j) * 5;
-    if (__builtin_bit_cast(unsigned long long, C[3]) == kSlicDead) return;
-    const int cx = min(max((int)(C[3] / (double)cell_px), 0), gx - 1), cy = min(max((int)(C[4] / (double)cell_px), 0), gy - 1);
-    const size_t cell = ((size_t)f * gy + cy) * gx + cx;
-    const int slot = atomicAdd(&cell_cnt[cell], 1);
-    if (slot < kSlicCellCap) cell_list[cell * kSlicCellCap + slot] = j;
-    else overflow[f] = 1;
-}
-
-// One workgroup per tile of kSlicTW x kSlicTH pixels.  The cells that can hold a candidate of any pixel of the tile
-// (the tile's cell range grown by one) are staged in LDS once -- counts, centre indices and the centres themselves --
-// and every thread then works through its pixels (one column, kSlicTH / 4 rows) against the 3 x 3 cells around each.
+// One workgroup per tile of kSlicTW x kSlicTH pixels.  Staged in LDS once per tile: the entries (centre index, centre,
+// integer window [k0, k1) x [l0, l1) = the reference's loop bounds, slic_window) of the cells that can hold a candidate
+// of any pixel of the tile (the tile's cell range grown by one); per cell the flat list of the entries of the 3 x 3 cells
+// around it (at most 32 -- a cell whose list is longer sends the tile to the slow walk); and, as bit masks over those
+// lists, which entries' windows hold a given column (per cell row and tile column) and a given row (per cell column and
+// tile row).  A pixel's candidates are then the AND of two masks -- about 4 of the 9 entries around it -- and a thread
+// walks only over the set bits: every trip of the loop computes a distance that is needed (the loop over all nine ran
+// the arithmetic for every lane whenever any lane's candidate passed: 322 -> 180 VALU instructions per 64 pixels).
 // One sweep keeps the smallest and second smallest un-rooted distance; only if the second is inside the band around
-// the first (ties included) does the pixel take the exact second sweep.  The winners' L, a, b, x, y, 1 are summed
-// per staged centre in LDS (32-bit: a tile holds at most 1024 pixels) and flushed with one global atomicAdd per
-// non-zero entry, so no separate accumulation pass over the image is needed.
-constexpr int kSlicTW = 64, kSlicTH = 16, kSlicMaxCells = 64;   // 35 KB of LDS; steps below 8 can exceed 64 cells and take the global walk
+// the first (ties included) does the pixel take the exact second sweep.
+//
+// The winners' L, a, b, x, y, 1 are summed per staged centre in LDS (32-bit: a tile holds at most 2048 pixels) and
+// flushed with one global atomicAdd per non-zero entry, so no separate accumulation pass over the image is needed.
+// The lanes of a wave are 64 neighbouring pixels of one row: most of them add to the SAME centre, and same-address LDS
+// atomics of one instruction are served one lane after the other (measured: a quarter of the kernel at 18-pixel
+// superpixels, half of it at 68).  So a thread works down a column (kSlicTH / 4 rows), sums the run of equal winners in
+// registers and adds a run to the table when it ends.  (Several copies of the table, lane & 3: slower -- LDS, occupancy.)
+#ifndef DCMT_SLIC_TH
+#define DCMT_SLIC_TH 32
+#endif
+constexpr int kSlicTW = 64, kSlicTH = DCMT_SLIC_TH, kSlicMaxCells = 64;   // steps below 8 can exceed 64 cells and take the slow walk
+constexpr int kSlicEntries = kSlicMaxCells * kSlicCellCap;
+constexpr int kSlicListCap = 9 * kSlicCellCap;
+constexpr int kSlicMaskBits = 32;
+constexpr int kSlicInnerX = 12, kSlicInnerY = 8;                // cells a tile's own pixels may span (more: slow walk)
+static_assert(kSlicEntries <= 256, "entry numbers are stored as bytes");
 
 __global__ __launch_bounds__(256)
 void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ centers, const int* __restrict__ cell_cnt,
                    const int* __restrict__ cell_list, const int* __restrict__ overflow, int* __restrict__ labels,
                    unsigned long long* __restrict__ sums, int rows, int cols, int step, int nc, int n, int gx, int gy, int cell_px)
 {
-    __shared__ double s_c[kSlicMaxCells * kSlicCellCap][5];
-    __shared__ int s_idx[kSlicMaxCells * kSlicCellCap];
-    __shared__ unsigned s_acc[kSlicMaxCells * kSlicCellCap][6];
+    __shared__ __attribute__((aligned(16))) double s_c[kSlicEntries][6];      // L, a, b, x, y (+ pad: 16-byte rows)
+    __shared__ int4 s_win[kSlicEntries];
+    __shared__ int s_idx[kSlicEntries];
+    __shared__ unsigned s_acc[kSlicEntries][6];
     __shared__ int s_cnt[kSlicMaxCells];
+    __shared__ __attribute__((aligned(4))) uint8_t s_list[kSlicMaxCells][kSlicListCap];
+    __shared__ int s_nlist[kSlicMaxCells];
+    __shared__ unsigned s_xmask[kSlicInnerY][kSlicTW];
+    __shared__ unsigned s_ymask[kSlicInnerX][kSlicTH];
+    __shared__ int s_slow;
     const int f = blockIdx.z, tx0 = blockIdx.x * kSlicTW, ty0 = blockIdx.y * kSlicTH;
-    const int cxa = max(tx0 / cell_px - 1, 0), cxb = min((min(tx0 + kSlicTW, cols) - 1) / cell_px + 1, gx - 1);
-    const int cya = max(ty0 / cell_px - 1, 0), cyb = min((min(ty0 + kSlicTH, rows) - 1) / cell_px + 1, gy - 1);
-    const int ncx = cxb - cxa + 1, ncells = ncx * (cyb - cya + 1);
-    const bool all = overflow[f] != 0 || ncells > kSlicMaxCells;       // walk every centre from global memory instead
+    const int tx1 = min(tx0 + kSlicTW, cols), ty1 = min(ty0 + kSlicTH, rows);          // the tile's pixels: [tx0, tx1) x [ty0, ty1)
+    const int icx0 = tx0 / cell_px, icx1 = (tx1 - 1) / cell_px, icy0 = ty0 / cell_px, icy1 = (ty1 - 1) / cell_px;   // their cells
+    const int cxa = max(icx0 - 1, 0), cxb = min(icx1 + 1, gx - 1), cya = max(icy0 - 1, 0), cyb = min(icy1 + 1, gy - 1);
+    const int ncx = cxb - cxa + 1, ncy = cyb - cya + 1, ncells = ncx * ncy;
+    const int nix = icx1 - icx0 + 1, niy = icy1 - icy0 + 1;
     const double* CF = centers + (size_t)f * n * 5;
-    if (!all) {
-        for (int c = threadIdx.x; c < ncells; c += 256) {
-            const size_t cell = ((size_t)f * gy + cya + c / ncx) * gx + cxa + c % ncx;
-            s_cnt[c] = min(cell_cnt[cell], kSlicCellCap);
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < ncells * kSlicCellCap; e += 256) {
-            const int c = e / kSlicCellCap, k = e % kSlicCellCap;
-            if (k < s_cnt[c]) {
-                const size_t cell = ((size_t)f * gy + cya + c / ncx) * gx + cxa + c % ncx;
-                const int j = cell_list[cell * kSlicCellCap + k];
-                s_idx[e] = j;
-#pragma unroll
-                for (int q = 0; q < 5; ++q) s_c[e][q] = CF[(size_t)j * 5 + q];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) s_acc[e][q] = 0u;
-            }
-        }
-        __syncthreads();
-    }
     const int x = tx0 + (threadIdx.x & 63);
+    const int yb = ty0 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (kSlicTH / 4);   // wave-uniform: the row arithmetic stays scalar
     const double inc2 = 1.0 / ((double)nc * (double)nc), ins2 = 1.0 / ((double)step * (double)step), fx = x;
-    for (int r = 0; r < kSlicTH / 4; ++r) {
-        const int y = ty0 + (threadIdx.x >> 6) * (kSlicTH / 4) + r;
-        if (x >= cols || y >= rows) continue;
-        const size_t p = ((size_t)f * rows + y) * cols + x;
-        const uint8_t* px = lab + 3 * p;
-        const double p0 = px[0], p1 = px[1], p2 = px[2], fy = y;
-        // does the centre C cover the pixel (exactly the reference's loop bounds)?  if so, its un-rooted distance
-        auto probe = [&](const double* C, bool checked, double& q) -> bool {    // checked: the integer window already passed
-            const double cx = C[3], cy = C[4];
-            if (!checked) {
+
+    // ---- the slow walk: every centre, windows tested as the reference's loop bounds, sums straight to global memory
+    auto slow_walk = [&]() {
+        for (int r = 0; r < kSlicTH / 4; ++r) {
+            const int y = yb + r;
+            if (x >= cols || y >= rows) continue;
+            const size_t p = ((size_t)f * rows + y) * cols + x;
+            const uint8_t* px = lab + 3 * p;
+            const double p0 = px[0], p1 = px[1], p2 = px[2], fy = y;
+            auto probe = [&](const double* C, double& q) -> bool {
+                const double cx = C[3], cy = C[4];
                 if (__builtin_bit_cast(unsigned long long, cx) == kSlicDead) return false;
                 if (x < (int)(cx - (double)step) || !(fx < cx + (double)step) || y < (int)(cy - (double)step) || !(fy < cy + (double)step)) return false;
-            }
-            const double d0 = C[0] - p0, d1 = C[1] - p1, d2 = C[2] - p2, e0 = cx - fx, e1 = cy - fy;
-            q = (d0 * d0 + d1 * d1 + d2 * d2) * inc2 + (e0 * e0 + e1 * e1) * ins2;
-            return true;
-        };
-        double q1 = 1.0e300, q2 = 1.0e300;         // smallest and second smallest un-rooted distance
-        int e1 = -1;                                // entry (LDS slot, or centre index in the `all` walk) of the smallest
-        auto sweep = [&](auto&& visit) {
-            if (all) { for (int j = 0; j < n; ++j) visit(CF + (size_t)j * 5, j, false); return; }
-            const int lcx = x / cell_px - cxa, lcy = y / cell_px - cya;
-            for (int cy = max(lcy - 1, 0); cy <= min(lcy + 1, cyb - cya); ++cy)
-                for (int cx = max(lcx - 1, 0); cx <= min(lcx + 1, ncx - 1); ++cx) {
-                    const int c = cy * ncx + cx;
-                    for (int k = 0; k < s_cnt[c]; ++k) visit(s_c[c * kSlicCellCap + k], c * kSlicCellCap + k, false);
-                }
-        };
-        sweep([&](const double* C, int e, bool checked) {
-            double q;
-            if (!probe(C, checked, q)) return;
-            if (q < q1) { q2 = q1; q1 = q; e1 = e; } else if (q < q2) q2 = q;
-        });
-        int best;                                   // winning centre index
-        if (e1 < 0) {                               // no window reaches this pixel: it keeps its label and still counts for it
-            best = labels[p];
-            if (best < 0) continue;
-            e1 = -1;
-        } else if (q2 > q1 * (1.0 + 4.0e-12) + 1.0e-300) {
-            best = all ? e1 : s_idx[e1];
-        } else {                                    // inside the band: the reference's own arithmetic decides, (distance, index)
-            const double band = q1 * (1.0 + 4.0e-12) + 1.0e-300;
-            double dbest = 0.0;
-            best = 0x7fffffff;
-            int ebest = -1;
-            sweep([&](const double* C, int e, bool checked) {
+                const double d0 = C[0] - p0, d1 = C[1] - p1, d2 = C[2] - p2, e0 = cx - fx, e1 = cy - fy;
+                q = (d0 * d0 + d1 * d1 + d2 * d2) * inc2 + (e0 * e0 + e1 * e1) * ins2;
+                return true;
+            };
+            double q1 = 1.0e300, q2 = 1.0e300;
+            int best = -1;
+            for (int j = 0; j < n; ++j) {
                 double q;
-                if (!probe(C, checked, q) || q > band) return;
-                const int j = all ? e : s_idx[e];
-                const double d = slic_dist(C, x, y, px, (double)nc, (double)step);
-                if (ebest < 0 || d < dbest || (d == dbest && j < best)) { dbest = d; best = j; ebest = e; }
-            });
-            e1 = ebest;
-        }
-        if (e1 >= 0) labels[p] = best;
-        if (!all && e1 >= 0) {
-            atomicAdd(&s_acc[e1][0], (unsigned)px[0]); atomicAdd(&s_acc[e1][1], (unsigned)px[1]); atomicAdd(&s_acc[e1][2], (unsigned)px[2]);
-            atomicAdd(&s_acc[e1][3], (unsigned)x); atomicAdd(&s_acc[e1][4], (unsigned)y); atomicAdd(&s_acc[e1][5], 1u);
-        } else {
+                if (!probe(CF + (size_t)j * 5, q)) continue;
+                if (q < q1) { q2 = q1; q1 = q; best = j; } else if (q < q2) q2 = q;
+            }
+            if (best < 0) {                             // no window reaches this pixel: it keeps its label and still counts for it
+                best = labels[p];
+                if (best < 0) continue;
+            } else {
+                const double band = q1 * (1.0 + 4.0e-12) + 1.0e-300;
+                if (!(q2 > band)) {                     // inside the band: the reference's own arithmetic decides, (distance, index)
+                    double dbest = 0.0;
+                    best = -1;
+                    for (int j = 0; j < n; ++j) {
+                        double q;
+                        if (!probe(CF + (size_t)j * 5, q) || q > band) continue;
+                        const double d = slic_dist(CF + (size_t)j * 5, x, y, px, (double)nc, (double)step);
+                        if (best < 0 || d < dbest) { dbest = d; best = j; }      // ascending j: the first of equal distances stays
+                    }
+                }
+                labels[p] = best;
+            }
             unsigned long long* sj = sums + ((size_t)f * n + best) * 6;
             atomicAdd(&sj[0], (unsigned long long)px[0]); atomicAdd(&sj[1], (unsigned long long)px[1]); atomicAdd(&sj[2], (unsigned long long)px[2]);
             atomicAdd(&sj[3], (unsigned long long)x); atomicAdd(&sj[4], (unsigned long long)y); atomicAdd(&sj[5], 1ull);
         }
+    };
+    if (overflow[f] != 0 || ncells > kSlicMaxCells || nix > kSlicInnerX || niy > kSlicInnerY) { slow_walk(); return; }   // block-uniform
+
+    // ---- staging
+    if (threadIdx.x == 0) s_slow = 0;
+    for (int c = threadIdx.x; c < ncells; c += 256) {
+        const size_t cell = ((size_t)f * gy + cya + c / ncx) * gx + cxa + c % ncx;
+        s_cnt[c] = min(cell_cnt[cell], kSlicCellCap);
     }
-    if (!all) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < ncells * kSlicCellCap; e += 256) {
-            if (e % kSlicCellCap < s_cnt[e / kSlicCellCap] && s_acc[e][5] != 0u) {
-                unsigned long long* sj = sums + ((size_t)f * n + s_idx[e]) * 6;
+    __syncthreads();
+    for (int e = threadIdx.x; e < ncells * kSlicCellCap; e += 256) {
+        const int c = e / kSlicCellCap, k = e % kSlicCellCap;
+        if (k < s_cnt[c]) {
+            const size_t cell = ((size_t)f * gy + cya + c / ncx) * gx + cxa + c % ncx;
+            const int j = cell_list[cell * kSlicCellCap + k];
+            s_idx[e] = j;
+            double C[5];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) atomicAdd(&sj[q], (unsigned long long)s_acc[e][q]);
+            for (int q = 0; q < 5; ++q) { C[q] = CF[(size_t)j * 5 + q]; s_c[e][q] = C[q]; }
+            int k0 = 0, k1 = 0, l0 = 0, l1 = 0;
+            if (!slic_window(C, step, rows, cols, k0, k1, l0, l1)) { k0 = k1 = l0 = l1 = 0; }     // dead or empty: holds no pixel
+            s_win[e] = make_int4(k0, k1 - k0, l0, l1 - l0);                                       // origin and extent: one unsigned compare each
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s_acc[e][q] = 0u;
+        }
+    }
+    // the candidates of the pixels of cell c: the entries of the 3 x 3 staged cells around it
+    for (int c = threadIdx.x; c < ncells; c += 256) {
+        const int ccx = c % ncx, ccy = c / ncx;
+        int m = 0;
+        for (int cy = max(ccy - 1, 0); cy <= min(ccy + 1, ncy - 1); ++cy)
+            for (int cx = max(ccx - 1, 0); cx <= min(ccx + 1, ncx - 1); ++cx) {
+                const int d = cy * ncx + cx;
+                for (int k = 0; k < s_cnt[d]; ++k) s_list[c][m++] = (uint8_t)(d * kSlicCellCap + k);
             }
+        s_nlist[c] = m;
+        if (m > kSlicMaskBits) s_slow = 1;
+    }
+    __syncthreads();
+    if (s_slow) { slow_walk(); return; }                                 // block-uniform
+    // which entries of its cell's list hold tile column xx (per cell row iy) / tile row yy (per cell column ix)
+    for (int t = threadIdx.x; t < niy * kSlicTW; t += 256) {
+        const int iy = t / kSlicTW, xx = t % kSlicTW, gxx = tx0 + xx;
+        unsigned m = 0u;
+        if (gxx < cols) {
+            const int c = (icy0 + iy - cya) * ncx + (gxx / cell_px - cxa);
+            for (int i = 0; i < s_nlist[c]; ++i) { const int4 w = s_win[s_list[c][i]]; m |= ((unsigned)(gxx - w.x) < (unsigned)w.y ? 1u : 0u) << i; }
+        }
+        s_xmask[iy][xx] = m;
+    }
+    for (int t = threadIdx.x; t < nix * kSlicTH; t += 256) {
+        const int ix = t / kSlicTH, yy = t % kSlicTH, gyy = ty0 + yy;
+        unsigned m = 0u;
+        if (gyy < rows) {
+            const int c = (gyy / cell_px - cya) * ncx + (icx0 + ix - cxa);
+            for (int i = 0; i < s_nlist[c]; ++i) { const int4 w = s_win[s_list[c][i]]; m |= ((unsigned)(gyy - w.z) < (unsigned)w.w ? 1u : 0u) << i; }
+        }
+        s_ymask[ix][yy] = m;
+    }
+    __syncthreads();
+
+    if (x < cols) {
+        const int lcx = x / cell_px - cxa, ix = x / cell_px - icx0, xx = x - tx0;
+        int run = -1;                                // entry of the current run of equal winners down this column
+        unsigned rl = 0, ra = 0, rb = 0, ry = 0, rn = 0;
+        auto flush = [&]() {
+            if (run >= 0) {
+                atomicAdd(&s_acc[run][0], rl); atomicAdd(&s_acc[run][1], ra); atomicAdd(&s_acc[run][2], rb);
+                atomicAdd(&s_acc[run][3], rn * (unsigned)x); atomicAdd(&s_acc[run][4], ry); atomicAdd(&s_acc[run][5], rn);
+            }
+        };
+        for (int r = 0; r < kSlicTH / 4; ++r) {
+            const int y = yb + r;
+            if (y >= rows) break;
+            const size_t p = ((size_t)f * rows + y) * cols + x;
+            const uint8_t* px = lab + 3 * p;
+            const unsigned u0 = px[0], u1 = px[1], u2 = px[2];
+            const double p0 = u0, p1 = u1, p2 = u2, fy = y;
+            const int cy = y / cell_px;
+            const uint8_t* list = s_list[(cy - cya) * ncx + lcx];
+            const unsigned cand = s_xmask[cy - icy0][xx] & s_ymask[ix][y - ty0];   // the entries whose windows hold this pixel
+            auto dist2 = [&](int e) -> double {        // the un-rooted distance to entry e
+                const double* C = s_c[e];
+                const double d0 = C[0] - p0, d1 = C[1] - p1, d2 = C[2] - p2, e0 = C[3] - fx, e1 = C[4] - fy;
+                return (d0 * d0 + d1 * d1 + d2 * d2) * inc2 + (e0 * e0 + e1 * e1) * ins2;
+            };
+            if (cand == 0u) {                           // no window reaches this pixel: it keeps its label and still counts for it
+                const int old = labels[p];
+                if (old >= 0) {
+                    unsigned long long* sj = sums + ((size_t)f * n + old) * 6;
+                    atomicAdd(&sj[0], (unsigned long long)u0); atomicAdd(&sj[1], (unsigned long long)u1); atomicAdd(&sj[2], (unsigned long long)u2);
+                    atomicAdd(&sj[3], (unsigned long long)x); atomicAdd(&sj[4], (unsigned long long)y); atomicAdd(&sj[5], 1ull);
+                }
+                continue;
+            }
+            double q1 = 1.0e300, q2 = 1.0e300;         // smallest and second smallest un-rooted distance
+            int e1 = -1;                                // entry of the smallest
+            for (unsigned m = cand; m != 0u; m &= m - 1u) {
+                const int e = list[__builtin_ctz(m)];
+                const double q = dist2(e);
+                if (q < q1) { q2 = q1; q1 = q; e1 = e; } else if (q < q2) q2 = q;
+            }
+            const double band = q1 * (1.0 + 4.0e-12) + 1.0e-300;
+            if (!(q2 > band)) {                         // inside the band: the reference's own arithmetic decides, (distance, index)
+                double dbest = 0.0;
+                int jbest = 0x7fffffff;
+                e1 = -1;
+                for (unsigned m = cand; m != 0u; m &= m - 1u) {
+                    const int e = list[__builtin_ctz(m)];
+                    if (dist2(e) > band) continue;
+                    const int j = s_idx[e];
+                    const double d = slic_dist(s_c[e], x, y, px, (double)nc, (double)step);
+                    if (e1 < 0 || d < dbest || (d == dbest && j < jbest)) { dbest = d; jbest = j; e1 = e; }
+                }
+            }
+            labels[p] = s_idx[e1];
+            if (e1 != run) { flush(); run = e1; rl = ra = rb = ry = rn = 0u; }
+            rl += u0; ra += u1; rb += u2; ry += (unsigned)y; rn += 1u;
+        }
+        flush();
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ncells * kSlicCellCap; e += 256) {
+        if (e % kSlicCellCap < s_cnt[e / kSlicCellCap] && s_acc[e][5] != 0u) {
+            unsigned long long* sj = sums + ((size_t)f * n + s_idx[e]) * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) atomicAdd(&sj[q], (unsigned long long)s_acc[e][q]);
         }
     }
 }
 
-__global__ void k_slic_norm(const unsigned long long* __restrict__ sums, double* __restrict__ centers, int total)
+// End of an iteration, one launch: centre = sums / count in f64 (dead without pixels); the sums are left zeroed for the next
+// iteration; the new centre is binned into the OTHER cell set (zeroed by the previous launch of this kernel, or by the host
+// before the first), and the cell set the assignment has just read is zeroed for the iteration after the next.  Threads
+// beyond the centres only zero.  (Separately -- two memsets, a binning and a normalising kernel -- these were four small
+// dependent operations per iteration.)
+__global__ void k_slic_norm_bin(unsigned long long* __restrict__ sums, double* __restrict__ centers, int n, int batch,
+                                int* __restrict__ next_cnt, int* __restrict__ next_list, int* __restrict__ next_overflow,
+                                int* __restrict__ used_cnt, int n_used, int cell_px, int gx, int gy)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= total) return;
-    const unsigned long long* s = sums + (size_t)c * 6;
-    double* C = centers + (size_t)c * 5;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_used) used_cnt[t] = 0;               // counts and, right behind them, the overflow flags
+    if (t >= n * batch) return;
+    unsigned long long* s = sums + (size_t)t * 6;
+    double* C = centers + (size_t)t * 5;
     if (s[5] == 0) {
         for (int q = 0; q < 5; ++q) C[q] = __builtin_bit_cast(double, kSlicDead);
         return;
     }
     const double cnt = (double)s[5];
-    for (int q = 0; q < 5; ++q) C[q] = __ddiv_rn((double)s[q], cnt);
+    double c[5];
+    for (int q = 0; q < 5; ++q) { c[q] = __ddiv_rn((double)s[q], cnt); C[q] = c[q]; }
+    for (int q = 0; q < 6; ++q) s[q] = 0ull;
+    slic_bin_one(c, t % n, t / n, next_cnt, next_list, next_overflow, cell_px, gx, gy);
 }
 
 }  // namespace dcmt
