@@ -850,8 +850,12 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
         double* cur = ctx->slic_centers[it & 1];
         double* nxt = ctx->slic_centers[(it + 1) & 1];
         const int a = it & 1, b = a ^ 1;
-        hipLaunchKernelGGL(k_slic_assign, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + kSlicTH - 1) / kSlicTH, batch), dim3(256), 0, st, d_lab, cur,
-                           set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
+        if (slic_tile_rows(cell_px) == 32)
+            hipLaunchKernelGGL(k_slic_assign<32>, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + 31) / 32, batch), dim3(256), 0, st, d_lab, cur,
+                               set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
+        else
+            hipLaunchKernelGGL(k_slic_assign<16>, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + 15) / 16, batch), dim3(256), 0, st, d_lab, cur,
+                               set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
         hipLaunchKernelGGL(k_slic_norm_bin, dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, st, ctx->slic_sums, nxt, n, batch,
                            set_cnt[b], set_list[b], set_ovf[b], set_cnt[a], (int)n_cnt, cell_px, gx, gy);
         DCMT_HIP(ctx, hipGetLastError());

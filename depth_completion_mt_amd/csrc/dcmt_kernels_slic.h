@@ -105,7 +105,7 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // Only candidates inside that band (exact ties included) are evaluated with slic_dist itself and compared as
 // (distance, centre index), which is the reference's rule.
 
-// One workgroup per tile of kSlicTW x kSlicTH pixels.  Staged in LDS once per tile: the entries (centre index, centre,
+// One workgroup per tile of kSlicTW x TH pixels.  Staged in LDS once per tile: the entries (centre index, centre,
 // integer window [k0, k1) x [l0, l1) = the reference's loop bounds, slic_window) of the cells that can hold a candidate
 // of any pixel of the tile (the tile's cell range grown by one); per cell the flat list of the entries of the 3 x 3 cells
 // around it (at most 32 -- a cell whose list is longer sends the tile to the slow walk); and, as bit masks over those
@@ -120,18 +120,20 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // flushed with one global atomicAdd per non-zero entry, so no separate accumulation pass over the image is needed.
 // The lanes of a wave are 64 neighbouring pixels of one row: most of them add to the SAME centre, and same-address LDS
 // atomics of one instruction are served one lane after the other (measured: a quarter of the kernel at 18-pixel
-// superpixels, half of it at 68).  So a thread works down a column (kSlicTH / 4 rows), sums the run of equal winners in
+// superpixels, half of it at 68).  So a thread works down a column (TH / 4 rows), sums the run of equal winners in
 // registers and adds a run to the table when it ends.  (Several copies of the table, lane & 3: slower -- LDS, occupancy.)
-#ifndef DCMT_SLIC_TH
-#define DCMT_SLIC_TH 32
-#endif
-constexpr int kSlicTW = 64, kSlicTH = DCMT_SLIC_TH, kSlicMaxCells = 64;   // steps below 8 can exceed 64 cells and take the slow walk
+// Tile height (template parameter TH): 32 rows = 8 per thread (longer runs, staging paid once per 2048 pixels) where the
+// tile's cells fit (steps from 11 up: at most 9 x 6 staged cells), 16 rows for the smaller steps (8 to 10: 11 x 5 cells);
+// steps below 8 can exceed 64 cells and take the slow walk.
+constexpr int kSlicTW = 64, kSlicMaxCells = 64;
+__host__ __device__ constexpr int slic_tile_rows(int step) { return step >= 11 ? 32 : 16; }
 constexpr int kSlicEntries = kSlicMaxCells * kSlicCellCap;
 constexpr int kSlicListCap = 9 * kSlicCellCap;
 constexpr int kSlicMaskBits = 32;
 constexpr int kSlicInnerX = 12, kSlicInnerY = 8;                // cells a tile's own pixels may span (more: slow walk)
 static_assert(kSlicEntries <= 256, "entry numbers are stored as bytes");
 
+template <int TH>
 __global__ __launch_bounds__(256)
 void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ centers, const int* __restrict__ cell_cnt,
                    const int* __restrict__ cell_list, const int* __restrict__ overflow, int* __restrict__ labels,
@@ -145,22 +147,22 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
     __shared__ __attribute__((aligned(4))) uint8_t s_list[kSlicMaxCells][kSlicListCap];
     __shared__ int s_nlist[kSlicMaxCells];
     __shared__ unsigned s_xmask[kSlicInnerY][kSlicTW];
-    __shared__ unsigned s_ymask[kSlicInnerX][kSlicTH];
+    __shared__ unsigned s_ymask[kSlicInnerX][TH];
     __shared__ int s_slow;
-    const int f = blockIdx.z, tx0 = blockIdx.x * kSlicTW, ty0 = blockIdx.y * kSlicTH;
-    const int tx1 = min(tx0 + kSlicTW, cols), ty1 = min(ty0 + kSlicTH, rows);          // the tile's pixels: [tx0, tx1) x [ty0, ty1)
+    const int f = blockIdx.z, tx0 = blockIdx.x * kSlicTW, ty0 = blockIdx.y * TH;
+    const int tx1 = min(tx0 + kSlicTW, cols), ty1 = min(ty0 + TH, rows);          // the tile's pixels: [tx0, tx1) x [ty0, ty1)
     const int icx0 = tx0 / cell_px, icx1 = (tx1 - 1) / cell_px, icy0 = ty0 / cell_px, icy1 = (ty1 - 1) / cell_px;   // their cells
     const int cxa = max(icx0 - 1, 0), cxb = min(icx1 + 1, gx - 1), cya = max(icy0 - 1, 0), cyb = min(icy1 + 1, gy - 1);
     const int ncx = cxb - cxa + 1, ncy = cyb - cya + 1, ncells = ncx * ncy;
     const int nix = icx1 - icx0 + 1, niy = icy1 - icy0 + 1;
     const double* CF = centers + (size_t)f * n * 5;
     const int x = tx0 + (threadIdx.x & 63);
-    const int yb = ty0 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (kSlicTH / 4);   // wave-uniform: the row arithmetic stays scalar
+    const int yb = ty0 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (TH / 4);   // wave-uniform: the row arithmetic stays scalar
     const double inc2 = 1.0 / ((double)nc * (double)nc), ins2 = 1.0 / ((double)step * (double)step), fx = x;
 
     // ---- the slow walk: every centre, windows tested as the reference's loop bounds, sums straight to global memory
     auto slow_walk = [&]() {
-        for (int r = 0; r < kSlicTH / 4; ++r) {
+        for (int r = 0; r < TH / 4; ++r) {
             const int y = yb + r;
             if (x >= cols || y >= rows) continue;
             const size_t p = ((size_t)f * rows + y) * cols + x;
@@ -252,8 +254,8 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
         }
         s_xmask[iy][xx] = m;
     }
-    for (int t = threadIdx.x; t < nix * kSlicTH; t += 256) {
-        const int ix = t / kSlicTH, yy = t % kSlicTH, gyy = ty0 + yy;
+    for (int t = threadIdx.x; t < nix * TH; t += 256) {
+        const int ix = t / TH, yy = t % TH, gyy = ty0 + yy;
         unsigned m = 0u;
         if (gyy < rows) {
             const int c = (gyy / cell_px - cya) * ncx + (icx0 + ix - cxa);
@@ -273,7 +275,7 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
                 atomicAdd(&s_acc[run][3], rn * (unsigned)x); atomicAdd(&s_acc[run][4], ry); atomicAdd(&s_acc[run][5], rn);
             }
         };
-        for (int r = 0; r < kSlicTH / 4; ++r) {
+        for (int r = 0; r < TH / 4; ++r) {
             const int y = yb + r;
             if (y >= rows) break;
             const size_t p = ((size_t)f * rows + y) * cols + x;
@@ -286,7 +288,9 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             auto dist2 = [&](int e) -> double {        // the un-rooted distance to entry e
                 const double* C = s_c[e];
                 const double d0 = C[0] - p0, d1 = C[1] - p1, d2 = C[2] - p2, e0 = C[3] - fx, e1 = C[4] - fy;
-                return (d0 * d0 + d1 * d1 + d2 * d2) * inc2 + (e0 * e0 + e1 * e1) * ins2;
+                // (a screening value: fused multiply-adds are as good as the separate roundings, the band below covers both)
+                const double sc = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)), ss = __builtin_fma(e1, e1, e0 * e0);
+                return __builtin_fma(ss, ins2, sc * inc2);
             };
             if (cand == 0u) {                           // no window reaches this pixel: it keeps its label and still counts for it
                 const int old = labels[p];
@@ -302,7 +306,9 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             for (unsigned m = cand; m != 0u; m &= m - 1u) {
                 const int e = list[__builtin_ctz(m)];
                 const double q = dist2(e);
-                if (q < q1) { q2 = q1; q1 = q; e1 = e; } else if (q < q2) q2 = q;
+                q2 = fmin(q2, fmax(q, q1));             // (q == q1 leaves q2 == q1: a tie goes to the exact sweep)
+                e1 = q < q1 ? e : e1;
+                q1 = fmin(q1, q);
             }
             const double band = q1 * (1.0 + 4.0e-12) + 1.0e-300;
             if (!(q2 > band)) {                         // inside the band: the reference's own arithmetic decides, (distance, index)
