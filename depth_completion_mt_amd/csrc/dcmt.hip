@@ -850,7 +850,10 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
         double* cur = ctx->slic_centers[it & 1];
         double* nxt = ctx->slic_centers[(it + 1) & 1];
         const int a = it & 1, b = a ^ 1;
-        if (slic_tile_rows(cell_px) == 32)
+        if (slic_tile_rows(cell_px) == 64)
+            hipLaunchKernelGGL(k_slic_assign<64>, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + 63) / 64, batch), dim3(256), 0, st, d_lab, cur,
+                               set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
+        else if (slic_tile_rows(cell_px) == 32)
             hipLaunchKernelGGL(k_slic_assign<32>, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + 31) / 32, batch), dim3(256), 0, st, d_lab, cur,
                                set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
         else

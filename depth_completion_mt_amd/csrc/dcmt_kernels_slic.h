@@ -116,17 +116,17 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // One sweep keeps the smallest and second smallest un-rooted distance; only if the second is inside the band around
 // the first (ties included) does the pixel take the exact second sweep.
 //
-// The winners' L, a, b, x, y, 1 are summed per staged centre in LDS (32-bit: a tile holds at most 2048 pixels) and
+// The winners' L, a, b, x, y, 1 are summed per staged centre in LDS (32-bit: a tile holds at most 4096 pixels) and
 // flushed with one global atomicAdd per non-zero entry, so no separate accumulation pass over the image is needed.
 // The lanes of a wave are 64 neighbouring pixels of one row: most of them add to the SAME centre, and same-address LDS
 // atomics of one instruction are served one lane after the other (measured: a quarter of the kernel at 18-pixel
 // superpixels, half of it at 68).  So a thread works down a column (TH / 4 rows), sums the run of equal winners in
 // registers and adds a run to the table when it ends.  (Several copies of the table, lane & 3: slower -- LDS, occupancy.)
-// Tile height (template parameter TH): 32 rows = 8 per thread (longer runs, staging paid once per 2048 pixels) where the
-// tile's cells fit (steps from 11 up: at most 9 x 6 staged cells), 16 rows for the smaller steps (8 to 10: 11 x 5 cells);
-// steps below 8 can exceed 64 cells and take the slow walk.
+// Tile height (template parameter TH): as tall as the tile's cells fit -- the staging is paid once per tile and a thread's
+// runs get longer -- 64 rows = 16 per thread for steps from 16 up (at most 7 x 7 staged cells), 32 for steps 11 to 15
+// (9 x 6), 16 for steps 8 to 10 (11 x 5); steps below 8 can exceed 64 cells and take the slow walk.
 constexpr int kSlicTW = 64, kSlicMaxCells = 64;
-__host__ __device__ constexpr int slic_tile_rows(int step) { return step >= 11 ? 32 : 16; }
+__host__ __device__ constexpr int slic_tile_rows(int step) { return step >= 16 ? 64 : (step >= 11 ? 32 : 16); }
 constexpr int kSlicEntries = kSlicMaxCells * kSlicCellCap;
 constexpr int kSlicListCap = 9 * kSlicCellCap;
 constexpr int kSlicMaskBits = 32;
@@ -230,38 +230,52 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             for (int q = 0; q < 6; ++q) s_acc[e][q] = 0u;
         }
     }
-    // the candidates of the pixels of cell c: the entries of the 3 x 3 staged cells around it
-    for (int c = threadIdx.x; c < ncells; c += 256) {
-        const int ccx = c % ncx, ccy = c / ncx;
-        int m = 0;
-        for (int cy = max(ccy - 1, 0); cy <= min(ccy + 1, ncy - 1); ++cy)
-            for (int cx = max(ccx - 1, 0); cx <= min(ccx + 1, ncx - 1); ++cx) {
-                const int d = cy * ncx + cx;
-                for (int k = 0; k < s_cnt[d]; ++k) s_list[c][m++] = (uint8_t)(d * kSlicCellCap + k);
-            }
-        s_nlist[c] = m;
-        if (m > kSlicMaskBits) s_slow = 1;
+    // the candidates of the pixels of cell c: the entries of the 3 x 3 staged cells around it, row by row.  One thread per
+    // (cell, neighbour): its entries start behind those of the neighbours before it.
+    for (int t = threadIdx.x; t < ncells * 9; t += 256) {
+        const int c = t / 9, nb = t - 9 * c, ccx = c % ncx, ccy = c / ncx;
+        int off = 0, mine = 0, dmine = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int cy = ccy + q / 3 - 1, cx = ccx + q % 3 - 1;
+            const bool ok = cy >= 0 && cy < ncy && cx >= 0 && cx < ncx;
+            const int d = ok ? cy * ncx + cx : 0;
+            const int cnt = ok ? s_cnt[d] : 0;
+            off += q < nb ? cnt : 0;
+            if (q == nb) { mine = cnt; dmine = d; }
+        }
+        for (int k = 0; k < mine; ++k) s_list[c][off + k] = (uint8_t)(dmine * kSlicCellCap + k);
+        if (nb == 8) {
+            s_nlist[c] = off + mine;
+            if (off + mine > kSlicMaskBits) s_slow = 1;
+        }
     }
     __syncthreads();
     if (s_slow) { slow_walk(); return; }                                 // block-uniform
-    // which entries of its cell's list hold tile column xx (per cell row iy) / tile row yy (per cell column ix)
+    // which entries of its cell's list hold tile column xx (per cell row iy) / tile row yy (per cell column ix); four entries
+    // per trip (their window reads are independent; list bytes past the end are in range and masked out)
+    auto window_mask = [&](int c, int v, bool rows_of_window) -> unsigned {
+        const int nl = s_nlist[c];
+        const unsigned* lw = reinterpret_cast<const unsigned*>(s_list[c]);
+        unsigned m = 0u;
+        for (int i = 0; i < nl; i += 4) {
+            const unsigned w4 = lw[i >> 2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int4 w = s_win[(w4 >> (8 * k)) & 0xffu];
+                const bool in = rows_of_window ? (unsigned)(v - w.z) < (unsigned)w.w : (unsigned)(v - w.x) < (unsigned)w.y;
+                m |= (in && i + k < nl ? 1u : 0u) << (i + k);
+            }
+        }
+        return m;
+    };
     for (int t = threadIdx.x; t < niy * kSlicTW; t += 256) {
         const int iy = t / kSlicTW, xx = t % kSlicTW, gxx = tx0 + xx;
-        unsigned m = 0u;
-        if (gxx < cols) {
-            const int c = (icy0 + iy - cya) * ncx + (gxx / cell_px - cxa);
-            for (int i = 0; i < s_nlist[c]; ++i) { const int4 w = s_win[s_list[c][i]]; m |= ((unsigned)(gxx - w.x) < (unsigned)w.y ? 1u : 0u) << i; }
-        }
-        s_xmask[iy][xx] = m;
+        s_xmask[iy][xx] = gxx < cols ? window_mask((icy0 + iy - cya) * ncx + (gxx / cell_px - cxa), gxx, false) : 0u;
     }
     for (int t = threadIdx.x; t < nix * TH; t += 256) {
         const int ix = t / TH, yy = t % TH, gyy = ty0 + yy;
-        unsigned m = 0u;
-        if (gyy < rows) {
-            const int c = (gyy / cell_px - cya) * ncx + (icx0 + ix - cxa);
-            for (int i = 0; i < s_nlist[c]; ++i) { const int4 w = s_win[s_list[c][i]]; m |= ((unsigned)(gyy - w.z) < (unsigned)w.w ? 1u : 0u) << i; }
-        }
-        s_ymask[ix][yy] = m;
+        s_ymask[ix][yy] = gyy < rows ? window_mask((gyy / cell_px - cya) * ncx + (icx0 + ix - cxa), gyy, true) : 0u;
     }
     __syncthreads();
 
