@@ -127,11 +127,11 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // (9 x 6), 16 for steps 8 to 10 (11 x 5); steps below 8 can exceed 64 cells and take the slow walk.
 constexpr int kSlicTW = 64, kSlicMaxCells = 64;
 __host__ __device__ constexpr int slic_tile_rows(int step) { return step >= 16 ? 64 : (step >= 11 ? 32 : 16); }
-constexpr int kSlicEntries = kSlicMaxCells * kSlicCellCap;
+constexpr int kSlicEntries = 128;                                // staged centres per tile, numbered densely (more: slow walk)
 constexpr int kSlicListCap = 9 * kSlicCellCap;
 constexpr int kSlicMaskBits = 32;
 constexpr int kSlicInnerX = 12, kSlicInnerY = 8;                // cells a tile's own pixels may span (more: slow walk)
-static_assert(kSlicEntries <= 256, "entry numbers are stored as bytes");
+static_assert(kSlicEntries <= 256 && (kSlicEntries & (kSlicEntries - 1)) == 0, "entry numbers are stored as bytes; stale list bytes are masked into range");
 
 template <int TH>
 __global__ __launch_bounds__(256)
@@ -143,12 +143,12 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
     __shared__ int4 s_win[kSlicEntries];
     __shared__ int s_idx[kSlicEntries];
     __shared__ unsigned s_acc[kSlicEntries][6];
-    __shared__ int s_cnt[kSlicMaxCells];
+    __shared__ int s_cnt[kSlicMaxCells], s_base[kSlicMaxCells + 1];       // entries of cell c: s_base[c] .. s_base[c] + s_cnt[c] - 1
     __shared__ __attribute__((aligned(4))) uint8_t s_list[kSlicMaxCells][kSlicListCap];
     __shared__ int s_nlist[kSlicMaxCells];
     __shared__ unsigned s_xmask[kSlicInnerY][kSlicTW];
     __shared__ unsigned s_ymask[kSlicInnerX][TH];
-    __shared__ int s_slow;
+    __shared__ int s_slow, s_slow2;                  // too many entries / too long a list (separate flags: each is read behind its own barrier)
     const int f = blockIdx.z, tx0 = blockIdx.x * kSlicTW, ty0 = blockIdx.y * TH;
     const int tx1 = min(tx0 + kSlicTW, cols), ty1 = min(ty0 + TH, rows);          // the tile's pixels: [tx0, tx1) x [ty0, ty1)
     const int icx0 = tx0 / cell_px, icx1 = (tx1 - 1) / cell_px, icy0 = ty0 / cell_px, icy1 = (ty1 - 1) / cell_px;   // their cells
@@ -208,15 +208,27 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
     if (overflow[f] != 0 || ncells > kSlicMaxCells || nix > kSlicInnerX || niy > kSlicInnerY) { slow_walk(); return; }   // block-uniform
 
     // ---- staging
-    if (threadIdx.x == 0) s_slow = 0;
+    if (threadIdx.x == 0) { s_slow = 0; s_slow2 = 0; }
     for (int c = threadIdx.x; c < ncells; c += 256) {
         const size_t cell = ((size_t)f * gy + cya + c / ncx) * gx + cxa + c % ncx;
         s_cnt[c] = min(cell_cnt[cell], kSlicCellCap);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < ncells * kSlicCellCap; e += 256) {
-        const int c = e / kSlicCellCap, k = e % kSlicCellCap;
+    if (threadIdx.x < 64) {                        // exclusive prefix of the counts over the (at most 64) staged cells, one wave
+        const int c = threadIdx.x, own = c < ncells ? s_cnt[c] : 0;
+        int inc = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); inc += c >= d ? o : 0; }
+        s_base[c] = inc - own;
+        if (c == 63) { s_base[64] = inc; if (inc > kSlicEntries) s_slow = 1; }
+    }
+    __syncthreads();
+    if (s_slow) { slow_walk(); return; }                                 // block-uniform
+    const int n_entries = s_base[64];
+    for (int t = threadIdx.x; t < ncells * kSlicCellCap; t += 256) {
+        const int c = t / kSlicCellCap, k = t % kSlicCellCap;
         if (k < s_cnt[c]) {
+            const int e = s_base[c] + k;
             const size_t cell = ((size_t)f * gy + cya + c / ncx) * gx + cxa + c % ncx;
             const int j = cell_list[cell * kSlicCellCap + k];
             s_idx[e] = j;
@@ -244,14 +256,14 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             off += q < nb ? cnt : 0;
             if (q == nb) { mine = cnt; dmine = d; }
         }
-        for (int k = 0; k < mine; ++k) s_list[c][off + k] = (uint8_t)(dmine * kSlicCellCap + k);
+        for (int k = 0; k < mine; ++k) s_list[c][off + k] = (uint8_t)(s_base[dmine] + k);
         if (nb == 8) {
             s_nlist[c] = off + mine;
-            if (off + mine > kSlicMaskBits) s_slow = 1;
+            if (off + mine > kSlicMaskBits) s_slow2 = 1;
         }
     }
     __syncthreads();
-    if (s_slow) { slow_walk(); return; }                                 // block-uniform
+    if (s_slow2) { slow_walk(); return; }                                 // block-uniform
     // which entries of its cell's list hold tile column xx (per cell row iy) / tile row yy (per cell column ix); four entries
     // per trip (their window reads are independent; list bytes past the end are in range and masked out)
     auto window_mask = [&](int c, int v, bool rows_of_window) -> unsigned {
@@ -262,7 +274,7 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             const unsigned w4 = lw[i >> 2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int4 w = s_win[(w4 >> (8 * k)) & 0xffu];
+                const int4 w = s_win[(w4 >> (8 * k)) & (kSlicEntries - 1)];
                 const bool in = rows_of_window ? (unsigned)(v - w.z) < (unsigned)w.w : (unsigned)(v - w.x) < (unsigned)w.y;
                 m |= (in && i + k < nl ? 1u : 0u) << (i + k);
             }
@@ -344,8 +356,8 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
         flush();
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < ncells * kSlicCellCap; e += 256) {
-        if (e % kSlicCellCap < s_cnt[e / kSlicCellCap] && s_acc[e][5] != 0u) {
+    for (int e = threadIdx.x; e < n_entries; e += 256) {
+        if (s_acc[e][5] != 0u) {
             unsigned long long* sj = sums + ((size_t)f * n + s_idx[e]) * 6;
 #pragma unroll
             for (int q = 0; q < 6; ++q) atomicAdd(&sj[q], (unsigned long long)s_acc[e][q]);
