@@ -751,6 +751,7 @@ int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t*
 {
     DCMT_ON_DEVICE(ctx);
     if (!ctx || !d_offsets || !T || !P || !d_sparse || n_points < 0 || (n_points > 0 && !d_points)) return DCMT_E_INVALID;
+    if ((uintptr_t)d_points % 16 != 0) return DCMT_E_INVALID;           // the 16-byte point records are read whole
     if (rows < 1 || cols < 1 || batch < 1 || batch > ctx->max_batch || rows > ctx->max_rows || cols > ctx->max_cols) return DCMT_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     ProjMats M;
@@ -762,9 +763,11 @@ int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t*
     if (n_points > 0)
         hipLaunchKernelGGL(k_project_scatter, dim3((n_points + 255) / 256), dim3(256), 0, st, d_points, d_offsets, n_points, batch, M,
                            winner, rows, cols);
-    size_t blocks = (n_px + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_project_resolve, dim3((unsigned)blocks), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
+    const size_t fe = (size_t)rows * cols;
+    if (fe % 2 == 0 && (uintptr_t)d_sparse % 8 == 0)
+        hipLaunchKernelGGL(k_project_resolve<2>, dim3((unsigned)((fe / 2 + 255) / 256), batch), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
+    else
+        hipLaunchKernelGGL(k_project_resolve<1>, dim3((unsigned)((fe + 255) / 256), batch), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
     DCMT_HIP(ctx, hipGetLastError());
     return DCMT_OK;
 }

@@ -143,9 +143,8 @@ __device__ __forceinline__ float dot4_rn(const float* m, float x, float y, float
 }
 
 // returns false if the point is dropped; otherwise pixel (u, v) and its depth
-__device__ __forceinline__ bool project_point(const ProjMats& M, const float* p, int rows, int cols, int& u, int& v, float& depth)
+__device__ __forceinline__ bool project_point(const ProjMats& M, float x, float y, float z, int rows, int cols, int& u, int& v, float& depth)
 {
-    const float x = p[0], y = p[1], z = p[2];
     const float tx = dot4_rn(M.T, x, y, z), ty = dot4_rn(M.T + 4, x, y, z), tz = dot4_rn(M.T + 8, x, y, z);
     if (!(tz > 0.0f)) return false;                                   // SL :487
     const float px = dot4_rn(M.P, tx, ty, tz), py = dot4_rn(M.P + 4, tx, ty, tz), pz = dot4_rn(M.P + 8, tx, ty, tz);
@@ -160,30 +159,52 @@ __global__ __launch_bounds__(256)
 void k_project_scatter(const float* __restrict__ pts, const int* __restrict__ offsets, int n_points, int batch,
                        ProjMats M, int* __restrict__ winner, int rows, int cols)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // frame of the workgroup's first point: one search per workgroup (offsets[f] <= i < offsets[f+1]); a thread's own frame is
+    // that one or, where sweeps end inside the workgroup's 256 points, a later one
+    __shared__ int s_lo;
+    const int i0 = blockIdx.x * 256;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = batch;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= i0) lo = mid; else hi = mid; }
+        s_lo = lo;
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
     if (i >= n_points) return;
-    int lo = 0, hi = batch;                       // frame f with offsets[f] <= i < offsets[f+1]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+    int lo = s_lo;
+    while (lo + 1 < batch && offsets[lo + 1] <= i) ++lo;
+    const float4 p = *reinterpret_cast<const float4*>(pts + 4 * (size_t)i);       // x, y, z, reflectance (16-byte records)
     int u, v; float d;
-    if (!project_point(M, pts + 4 * (size_t)i, rows, cols, u, v, d)) return;
+    if (!project_point(M, p.x, p.y, p.z, rows, cols, u, v, d)) return;
     atomicMax(&winner[((size_t)lo * rows + v) * cols + u], i - offsets[lo]);
 }
 
+// One thread per PW neighbouring pixels of one frame (grid: x over the frame, y = frame): 8-byte accesses where frames have an
+// even number of pixels.  Most pixels have no point and are a zero; the winners' depths are recomputed from their points.
+template <int PW>
 __global__ __launch_bounds__(256)
 void k_project_resolve(const float* __restrict__ pts, const int* __restrict__ offsets, ProjMats M,
                        const int* __restrict__ winner, float* __restrict__ sparse, int rows, int cols, int batch)
 {
-    const size_t fe = (size_t)rows * cols, n = fe * batch;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int w = winner[i];
-        float out = 0.0f;
-        if (w >= 0) {
-            const size_t f = i / fe;
+    const size_t fe = (size_t)rows * cols, f = blockIdx.y;
+    const size_t t = (blockIdx.x * (size_t)256 + threadIdx.x) * PW;
+    if (t >= fe) return;
+    const size_t i = f * fe + t;
+    int w[PW];
+    if constexpr (PW == 2) { const int2 ww = *reinterpret_cast<const int2*>(winner + i); w[0] = ww.x; w[1] = ww.y; }
+    else w[0] = winner[i];
+    float o[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        o[k] = 0.0f;
+        if (w[k] >= 0) {
+            const float4 p = *reinterpret_cast<const float4*>(pts + 4 * ((size_t)offsets[f] + w[k]));
             int u, v;
-            (void)project_point(M, pts + 4 * ((size_t)offsets[f] + w), rows, cols, u, v, out);
+            (void)project_point(M, p.x, p.y, p.z, rows, cols, u, v, o[k]);
         }
-        sparse[i] = out;
     }
+    if constexpr (PW == 2) *reinterpret_cast<float2*>(sparse + i) = make_float2(o[0], o[1]);
+    else sparse[i] = o[0];
 }
 
 // ---------------------------------------------------------------------------------

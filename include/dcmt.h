@@ -190,7 +190,8 @@ int dcmt_complete_labeled_f32_dev(dcmt_ctx *ctx, const float *d_src, const int32
  *     p = P * (t.x, t.y, t.z, 1);  uf = p.x / p.z,  vf = p.y / p.z                      (:499-503)
  *     if 0 <= uf < cols and 0 <= vf < rows:  image(int(vf), int(uf)) = p.z              (:506-518)
  * in file order, so a later point overwrites an earlier one that fell into the same pixel.
- * d_points: device, [n_points][4] f32 = x, y, z, reflectance -- the KITTI .bin layout the reference reads (:468-472);
+ * d_points: device, [n_points][4] f32 = x, y, z, reflectance -- the KITTI .bin layout the reference reads (:468-472),
+ * 16-byte aligned (every device allocation is; the records are read whole): DCMT_E_INVALID otherwise;
  * frame f owns points [d_offsets[f], d_offsets[f+1]) (device array of batch+1 ints, d_offsets[batch] == n_points).
  * T: 4x4, P: 3x4, both ROW-major host arrays (Eigen's default storage is column-major: pass the transposes' data()).
  * d_sparse: [batch][rows][cols] f32, written completely (0 = no point).  All arithmetic is f32, one rounding per
