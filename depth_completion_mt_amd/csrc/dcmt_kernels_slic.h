@@ -139,7 +139,7 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
                    const int* __restrict__ cell_list, const int* __restrict__ overflow, int* __restrict__ labels,
                    unsigned long long* __restrict__ sums, int rows, int cols, int step, int nc, int n, int gx, int gy, int cell_px)
 {
-    __shared__ __attribute__((aligned(16))) double s_c[kSlicEntries][6];      // L, a, b, x, y (+ pad: 16-byte rows)
+    __shared__ __attribute__((aligned(16))) double s_c[kSlicEntries][6];      // per staged centre: the affine form of its screening distance (below)
     __shared__ int4 s_win[kSlicEntries];
     __shared__ int s_idx[kSlicEntries];
     __shared__ unsigned s_acc[kSlicEntries][6];
@@ -159,6 +159,11 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
     const int x = tx0 + (threadIdx.x & 63);
     const int yb = ty0 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (TH / 4);   // wave-uniform: the row arithmetic stays scalar
     const double inc2 = 1.0 / ((double)nc * (double)nc), ins2 = 1.0 / ((double)step * (double)step), fx = x;
+    // bound of the rounding error of a screening distance in its affine form: every intermediate is below `mag` in magnitude
+    // (colour terms up to 3 * 255^2 / nc^2; tile-relative coordinates up to kSlicTW + 2 cells, TH + 2 cells) and fewer than 32
+    // roundings of 2^-53 relative each are involved
+    const double ext = (double)(kSlicTW + TH + 4 * cell_px);
+    const double delta = 0x1p-48 * (2.0 * 195075.0 * inc2 + 4.0 * ext * ext * ins2 + 1.0);
 
     // ---- the slow walk: every centre, windows tested as the reference's loop bounds, sums straight to global memory
     auto slow_walk = [&]() {
@@ -234,7 +239,13 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             s_idx[e] = j;
             double C[5];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { C[q] = CF[(size_t)j * 5 + q]; s_c[e][q] = C[q]; }
+            for (int q = 0; q < 5; ++q) C[q] = CF[(size_t)j * 5 + q];
+            // q(pixel) = |C_lab - p_lab|^2 / nc^2 + |C_xy - p_xy|^2 / step^2 = A + B . (L, a, b, x, y) + (a term of the pixel alone),
+            // with x, y relative to the tile's origin to keep the products small: five fused multiply-adds per candidate
+            const double cx = C[3] - (double)tx0, cy = C[4] - (double)ty0;
+            s_c[e][0] = -2.0 * C[0] * inc2; s_c[e][1] = -2.0 * C[1] * inc2; s_c[e][2] = -2.0 * C[2] * inc2;
+            s_c[e][3] = -2.0 * cx * ins2; s_c[e][4] = -2.0 * cy * ins2;
+            s_c[e][5] = (C[0] * C[0] + C[1] * C[1] + C[2] * C[2]) * inc2 + (cx * cx + cy * cy) * ins2;
             int k0 = 0, k1 = 0, l0 = 0, l1 = 0;
             if (!slic_window(C, step, rows, cols, k0, k1, l0, l1)) { k0 = k1 = l0 = l1 = 0; }     // dead or empty: holds no pixel
             s_win[e] = make_int4(k0, k1 - k0, l0, l1 - l0);                                       // origin and extent: one unsigned compare each
@@ -307,16 +318,15 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
             const size_t p = ((size_t)f * rows + y) * cols + x;
             const uint8_t* px = lab + 3 * p;
             const unsigned u0 = px[0], u1 = px[1], u2 = px[2];
-            const double p0 = u0, p1 = u1, p2 = u2, fy = y;
+            const double p0 = u0, p1 = u1, p2 = u2;
             const int cy = y / cell_px;
             const uint8_t* list = s_list[(cy - cya) * ncx + lcx];
             const unsigned cand = s_xmask[cy - icy0][xx] & s_ymask[ix][y - ty0];   // the entries whose windows hold this pixel
-            auto dist2 = [&](int e) -> double {        // the un-rooted distance to entry e
-                const double* C = s_c[e];
-                const double d0 = C[0] - p0, d1 = C[1] - p1, d2 = C[2] - p2, e0 = C[3] - fx, e1 = C[4] - fy;
-                // (a screening value: fused multiply-adds are as good as the separate roundings, the band below covers both)
-                const double sc = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)), ss = __builtin_fma(e1, e1, e0 * e0);
-                return __builtin_fma(ss, ins2, sc * inc2);
+            // screening value of entry e without the pixel's own term: A + B . (L, a, b, x, y)
+            const double fxl = xx, fyl = y - ty0;
+            auto affine = [&](int e) -> double {
+                const double* B = s_c[e];
+                return __builtin_fma(B[4], fyl, __builtin_fma(B[3], fxl, __builtin_fma(B[2], p2, __builtin_fma(B[1], p1, __builtin_fma(B[0], p0, B[5])))));
             };
             if (cand == 0u) {                           // no window reaches this pixel: it keeps its label and still counts for it
                 const int old = labels[p];
@@ -327,25 +337,30 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
                 }
                 continue;
             }
-            double q1 = 1.0e300, q2 = 1.0e300;         // smallest and second smallest un-rooted distance
+            double a1 = 1.0e300, a2 = 1.0e300;         // smallest and second smallest screening value
             int e1 = -1;                                // entry of the smallest
             for (unsigned m = cand; m != 0u; m &= m - 1u) {
                 const int e = list[__builtin_ctz(m)];
-                const double q = dist2(e);
-                q2 = fmin(q2, fmax(q, q1));             // (q == q1 leaves q2 == q1: a tie goes to the exact sweep)
-                e1 = q < q1 ? e : e1;
-                q1 = fmin(q1, q);
+                const double a = affine(e);
+                a2 = fmin(a2, fmax(a, a1));             // (a == a1 leaves a2 == a1: a tie goes to the exact sweep)
+                e1 = a < a1 ? e : e1;
+                a1 = fmin(a1, a);
             }
-            const double band = q1 * (1.0 + 4.0e-12) + 1.0e-300;
+            // the un-rooted distances themselves: + the pixel's own term.  They carry the rounding of the affine form (delta, an
+            // absolute bound); the reference's value is the root of the true sum to a few 1e-16 relative.  A minimum that is clear
+            // by more than the band has the same winner in the reference's arithmetic.
+            const double own = __builtin_fma(__builtin_fma(fyl, fyl, fxl * fxl), ins2, __builtin_fma(p2, p2, __builtin_fma(p1, p1, p0 * p0)) * inc2);
+            const double q1 = a1 + own, q2 = a2 + own;
+            const double band = q1 * (1.0 + 4.0e-12) + 4.0 * delta;
             if (!(q2 > band)) {                         // inside the band: the reference's own arithmetic decides, (distance, index)
                 double dbest = 0.0;
                 int jbest = 0x7fffffff;
                 e1 = -1;
                 for (unsigned m = cand; m != 0u; m &= m - 1u) {
                     const int e = list[__builtin_ctz(m)];
-                    if (dist2(e) > band) continue;
+                    if (affine(e) + own > band) continue;
                     const int j = s_idx[e];
-                    const double d = slic_dist(s_c[e], x, y, px, (double)nc, (double)step);
+                    const double d = slic_dist(CF + (size_t)j * 5, x, y, px, (double)nc, (double)step);
                     if (e1 < 0 || d < dbest || (d == dbest && j < jbest)) { dbest = d; jbest = j; e1 = e; }
                 }
             }
