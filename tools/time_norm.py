@@ -14,4 +14,5 @@ for name, p in (("plain", make_params()), ("normalize(0,80)", make_params(normal
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): ctx.complete_dev(d, o, p)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-    print(f"{name}: {B / dt:.0f} frames/s ({dt * 1e3:.3f} ms per 1024 frames)")
+    gbs = B * 352 * 1216 * 8 / dt / 1e9       # algorithmic: sparse frame in, dense frame out (the min-max pass re-reads the input: not counted)
+    print(f"{name}: {B / dt:.0f} frames/s ({dt * 1e3:.3f} ms per 1024 frames; {gbs:.0f} GB/s of the 8 B/px = {gbs / 8000:.3f} of 8 TB/s)")

@@ -20,4 +20,7 @@ for name, chain in (("project", False), ("project + normalize + complete", True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): run(chain)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-    print(f"{name}: {B / dt:.0f} sweeps/s, {B * N / dt / 1e9:.2f} G points/s ({dt * 1e3:.3f} ms per {B} sweeps)")
+    # algorithmic bytes of the projection: 16 B per point read, 4 B per pixel of the sparse image written (the chain adds 8 B/px)
+    gbs = B * (N * 16 + rows * cols * (12 if chain else 4)) / dt / 1e9
+    print(f"{name}: {B / dt:.0f} sweeps/s, {B * N / dt / 1e9:.2f} G points/s ({dt * 1e3:.3f} ms per {B} sweeps; "
+          f"{gbs:.0f} GB/s algorithmic = {gbs / 8000:.3f} of 8 TB/s)")

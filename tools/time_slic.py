@@ -13,5 +13,8 @@ for rows, cols, nsp, nc in ((352, 1216, 1200, 50), (375, 1242, 100, 40)):
     torch.cuda.synchronize(); t0 = time.perf_counter(); n = 3
     for _ in range(n): ctx.slic_labels_dev(imgs, step, nc, lab)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-    print(f"SLIC {cols}x{rows}, step {step}, nc {nc}, batch {B}: {B / dt:.0f} images/s ({dt * 1e3 / B:.3f} ms per image)")
+    # algorithmic bytes: every one of the 10 iterations reads the 3-byte Lab pixel and writes the 4-byte label
+    gbs = B * rows * cols * 70 / dt / 1e9
+    print(f"SLIC {cols}x{rows}, step {step}, nc {nc}, batch {B}: {B / dt:.0f} images/s ({dt * 1e3 / B:.3f} ms per image; "
+          f"{gbs:.0f} GB/s of the 70 B/px it must move = {gbs / 8000:.3f} of 8 TB/s)")
     ctx.close()
