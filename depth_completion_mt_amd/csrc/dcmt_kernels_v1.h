@@ -234,18 +234,18 @@ __device__ __forceinline__ float grey_dx(const uint8_t* g, int r, int c, int row
 // LDS_ROW: the workgroup first stages the whole right-image row (and the first pixel of the next one) in LDS: a sweep's
 // bytes then come from ds_read_u8 instead of four byte gathers through the texture path, which is what bound the first
 // version (1.42 ms per 256 pairs of 1242x375 with ~250 VALU instructions per pixel: the CU's address unit takes a 64-lane byte
-// load at a few lanes per cycle).  Dynamic LDS: cols + 1 bytes.
+// load at a few lanes per cycle).  Dynamic LDS: cols + 4 bytes.
 template <bool LDS_ROW>
 __global__ __launch_bounds__(256)
 void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                      float* __restrict__ out, int rows, int cols, int batch, StereoP P)
 {
-    extern __shared__ uint8_t s_row[];
+    extern __shared__ uint8_t s_row[];             // LDS_ROW: [0] pad, [1 .. n] the row (and the next row's first pixel), two pads
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if constexpr (LDS_ROW) {
         const uint8_t* g = right + (size_t)blockIdx.z * rows * cols + (size_t)i * cols;
         const int n = i + 1 < rows ? cols + 1 : cols;
-        for (int k = threadIdx.x; k < n; k += 256) s_row[k] = g[k];
+        for (int k = threadIdx.x; k < cols + 4; k += 256) s_row[k] = (k >= 1 && k <= n) ? g[k - 1] : (uint8_t)0;
         __syncthreads();
     }
     if (j >= cols) return;
@@ -260,16 +260,27 @@ void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict_
     for (int k = 0; k < P.iterations; ++k) {                                    // optimize_IG :809-841
         const float c = __fsub_rn((float)j, disp);
         const int c0 = (int)((double)c + 0.5);
-        if (c0 < 0 || c0 + 1 > cols || disp == 0.0f) continue;
         const int e0 = i * cols + c0, e1 = e0 + 1;                              // p00, p01 (p01 may be the next row's first pixel)
-        if (e1 >= fei) continue;
-        const bool wrap = c0 + 1 == cols;                                       // p01 = (i + 1, 0)
-        auto px = [&](int e) -> float { if constexpr (LDS_ROW) return (float)s_row[e - i * cols]; else return (float)gr[e]; };
-        const float g0 = px(e0), g1 = px(e1);
+        // the sweep leaves the disparity alone where the reference `continue`s; everything below is computed regardless, from a
+        // clamped column (no branch, one LDS round trip per sweep instead of three)
+        const bool live = !(c0 < 0 || c0 + 1 > cols || disp == 0.0f) && e1 < fei;
+        const int cc = min(max(c0, 0), cols - 1);
+        const bool wrap = cc + 1 == cols;                                       // p01 = (i + 1, 0)
+        float gm, g0, g1, gp;                                                   // g[e0-1], g[e0], g[e1], g[e1+1]
+        if constexpr (LDS_ROW) {
+            unsigned w;
+            __builtin_memcpy(&w, s_row + cc, 4);                                // bytes cc-1 .. cc+2 of the row (pad in front)
+            gm = (float)(w & 0xffu); g0 = (float)((w >> 8) & 0xffu); g1 = (float)((w >> 16) & 0xffu); gp = (float)(w >> 24);
+        } else {
+            const int b0 = i * cols + cc;
+            g0 = (float)gr[b0];
+            gm = (float)gr[max(b0 - 1, 0)];
+            g1 = (float)gr[min(b0 + 1, fei - 1)];
+            gp = (float)gr[min(b0 + 2, fei - 1)];
+        }
         // central differences (calculateMeasuementDerivatives :715-745): 0 on the image border
-        float dx0 = 0.0f, dx1 = 0.0f;
-        if (row_in && c0 >= 1 && c0 < cols - 1) dx0 = __fsub_rn(__fmul_rn(0.5f, g1), __fmul_rn(0.5f, px(e0 - 1)));
-        if (!wrap && row_in && c0 + 1 < cols - 1) dx1 = __fsub_rn(__fmul_rn(0.5f, px(e1 + 1)), __fmul_rn(0.5f, g0));   // (a wrapped p01 sits in column 0: border, 0)
+        const float dx0 = (row_in && cc >= 1 && cc < cols - 1) ? __fsub_rn(__fmul_rn(0.5f, g1), __fmul_rn(0.5f, gm)) : 0.0f;
+        const float dx1 = (!wrap && row_in && cc + 1 < cols - 1) ? __fsub_rn(__fmul_rn(0.5f, gp), __fmul_rn(0.5f, g0)) : 0.0f;   // (a wrapped p01 sits in column 0: border, 0)
         const float dc = __fsub_rn(c, (float)c0), dc1 = __fsub_rn(1.0f, dc);
         const float value = __fadd_rn(__fmul_rn(g0, dc1), __fmul_rn(g1, dc));
         const float dx = __fadd_rn(__fmul_rn(dx0, dc1), __fmul_rn(dx1, dc));
@@ -279,7 +290,8 @@ void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict_
         const float jcr = __fmul_rn(-1.0f, dx);                                 // J = -1 (:830-832)
         const float H = __fadd_rn(__fmul_rn(jcr, jcr), P.damp);
         const float b = __fmul_rn(jcr, error);
-        disp = __fadd_rn(disp, __fdiv_rn(-b, H));                               // :836-837
+        const float next = __fadd_rn(disp, __fdiv_rn(-b, H));                   // :836-837
+        disp = live ? next : disp;
     }
     float o = 0.0f;                                                             // retrieve_optimized_depth :868-880
     if (disp > 0.0f) { o = __fdiv_rn(bf, disp); if (o > P.max_depth) o = P.max_depth; }
