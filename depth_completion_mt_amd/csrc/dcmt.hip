@@ -790,9 +790,9 @@ int dcmt_stereo_refine_dev(dcmt_ctx* ctx, const float* d_depth, const uint8_t* d
     if (params->iterations > 1000) return DCMT_E_INVALID;
     StereoP P{params->baseline, params->focal, params->damp, params->max_depth, params->iterations < 0 ? 4 : params->iterations};
     if (rows > 65535 || batch > 65535) return DCMT_E_INVALID;                  // grid dimensions y, z
-    const dim3 sg((cols + 255) / 256, rows, batch);
-    if (cols + 4 <= 48 * 1024)      // the right-image row fits the workgroup's LDS
-        hipLaunchKernelGGL(k_stereo_refine<true>, sg, dim3(256), (size_t)cols + 4, (hipStream_t)stream, d_depth, d_left, d_right, d_refined, rows, cols, batch, P);
+    const dim3 sg((cols + 255) / 256, rows, batch), sg1(1, rows, batch);
+    if (cols + 4 <= 48 * 1024)      // the right-image row fits the workgroup's LDS: one workgroup stages it and walks the whole row
+        hipLaunchKernelGGL(k_stereo_refine<true>, sg1, dim3(256), (size_t)cols + 4, (hipStream_t)stream, d_depth, d_left, d_right, d_refined, rows, cols, batch, P);
     else
         hipLaunchKernelGGL(k_stereo_refine<false>, sg, dim3(256), 0, (hipStream_t)stream, d_depth, d_left, d_right, d_refined, rows, cols, batch, P);
     DCMT_HIP(ctx, hipGetLastError());

@@ -226,7 +226,9 @@ __device__ __forceinline__ float grey_dx(const uint8_t* g, int r, int c, int row
     return __fsub_rn(__fmul_rn(0.5f, (float)g[(size_t)r * cols + c + 1]), __fmul_rn(0.5f, (float)g[(size_t)r * cols + c - 1]));
 }
 
-// Grid: (ceil(cols / 256), rows, batch) -- one thread per pixel, no index divisions.  Per Gauss-Newton sweep the reference
+// Grid: (1, rows, batch) with the row in LDS -- one workgroup stages the right image's row once and its threads walk the whole
+// row, 256 columns at a time (five workgroups per 1242-pixel row, each staging the row, took 1.12 ms instead of 0.91) --
+// or (ceil(cols / 256), rows, batch) without; no index divisions.  Per Gauss-Newton sweep the reference
 // touches six right-image bytes (p00, p01 and the central differences at both); p01 is the neighbour of p00 in memory
 // (e1 = e0 + 1, also across the end of a row, which the reference's at<>() reads too), so the six are four distinct bytes:
 // g[e0-1], g[e0], g[e1], g[e1+1].  All arithmetic as in the oracle: one rounding per operation, IEEE divisions where the
@@ -241,18 +243,20 @@ void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict_
                      float* __restrict__ out, int rows, int cols, int batch, StereoP P)
 {
     extern __shared__ uint8_t s_row[];             // LDS_ROW: [0] pad, [1 .. n] the row (and the next row's first pixel), two pads
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    const int j0 = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if constexpr (LDS_ROW) {
         const uint8_t* g = right + (size_t)blockIdx.z * rows * cols + (size_t)i * cols;
         const int n = i + 1 < rows ? cols + 1 : cols;
         for (int k = threadIdx.x; k < cols + 4; k += 256) s_row[k] = (k >= 1 && k <= n) ? g[k - 1] : (uint8_t)0;
         __syncthreads();
     }
-    if (j >= cols) return;
-    const size_t fe = (size_t)rows * cols, idx = (size_t)blockIdx.z * fe + (size_t)i * cols + j;
+    const size_t fe = (size_t)rows * cols;
     const int fei = (int)fe;                                                    // a frame has < 2^29 pixels (dcmt_create)
     const float bf = __fmul_rn(P.baseline, P.focal);
     const uint8_t* gr = right + (size_t)blockIdx.z * fe;
+    // the grid's x extent times 256 threads may cover only part of the row: a thread takes every (gridDim.x * 256)-th column
+    for (int j = j0; j < cols; j += gridDim.x * 256) {
+    const size_t idx = (size_t)blockIdx.z * fe + (size_t)i * cols + j;
     const float d0 = depth[idx];
     float disp = d0 > 0.0f ? __fdiv_rn(bf, d0) : 0.0f;                          // get_initial_disparity :852-856
     const float lv = (float)left[idx];
@@ -296,6 +300,7 @@ void k_stereo_refine(const float* __restrict__ depth, const uint8_t* __restrict_
     float o = 0.0f;                                                             // retrieve_optimized_depth :868-880
     if (disp > 0.0f) { o = __fdiv_rn(bf, disp); if (o > P.max_depth) o = P.max_depth; }
     out[idx] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------
