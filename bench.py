@@ -200,6 +200,51 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
     return out
 
 
+def next_rows(torch, np, local_rank, d_src, d_dst, stream):
+    """The rows either side of the path (tools/time_norm.py, time_project.py, time_slic.py, time_stereo.py
+    are the stand-alone forms): N1 min-max normalisation fused in front, N2 LiDAR projection, N3 SLIC labels, N4 stereo
+    refinement -- each with the algorithmic bytes it must move and its fraction of the HBM peak."""
+    from depth_completion_mt_amd import Context, make_params, synth
+    out, cs = {}, stream.cuda_stream
+    B = d_src.shape[0]
+    c = Context(local_rank, ROWS, COLS, B)
+    pn = make_params(normalize=(0, 80))
+    ms = timed(torch, lambda: c.complete_dev(d_src, d_dst, pn, stream=cs), 10, stream)
+    out["N1_normalize_complete"] = {"workload": f"cv::normalize(0, 80) + img_completion, {COLS}x{ROWS}, {B} frames per step (SL/main_sl.cpp:370)",
+                                    "value": B * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(B * BYTES_PER_FRAME, ms)}
+    c.close()
+    rows, cols, Bp, N = 375, 1242, 256, 120000
+    pts = torch.from_numpy(np.concatenate([synth.synth_points(N, i) for i in range(8)])).cuda().repeat(Bp // 8, 1).contiguous()
+    off = torch.arange(0, (Bp + 1) * N, N, dtype=torch.int32, device="cuda")
+    sp = torch.empty((Bp, rows, cols), dtype=torch.float32, device="cuda")
+    c = Context(local_rank, rows, cols, Bp)
+    ms = timed(torch, lambda: c.project_points_dev(pts, off, synth.KITTI_T_VELO_TO_CAM, synth.KITTI_P2, rows, cols, sp, stream=cs), 10, stream)
+    out["N2_project"] = {"workload": f"velodyne sweep -> sparse depth image, {Bp} sweeps x {N} points -> {cols}x{rows} (SL/main_sl.cpp:478-520)",
+                         "value": Bp * 1e3 / ms, "unit": "sweeps/s", "roofline": hbm_roofline(Bp * (N * 16 + rows * cols * 4), ms)}
+    del pts, sp
+    trip = [synth.synth_stereo(rows, cols, i) for i in range(4)]
+    cu = lambda k: torch.from_numpy(np.stack([t[k] for t in trip])).cuda().repeat(Bp // 4, 1, 1).contiguous()
+    l, r, g = cu(0), cu(1), cu(2)
+    o = torch.empty_like(g)
+    ms = timed(torch, lambda: c.stereo_refine_dev(g, l, r, o, stream=cs), 10, stream)
+    out["N4_stereo_refine"] = {"workload": f"photometric refinement, {Bp} rectified pairs of {cols}x{rows}, 4 sweeps (SL/main_sl.cpp:715-885)",
+                               "value": Bp * 1e3 / ms, "unit": "pairs/s", "roofline": hbm_roofline(Bp * rows * cols * 10, ms)}
+    c.close()
+    del l, r, g, o
+    Bs = 64
+    for key, rows, cols, nsp, nc, name in (("N3_slic_lidar_camera", 352, 1216, 1200, 50, "LC/main_lc.cpp:188-200"), ("N3_slic_stereo_lidar", 375, 1242, 100, 40, "SL/main_sl.cpp:443")):
+        step = int(np.sqrt(rows * cols / nsp))
+        imgs = torch.from_numpy(np.ascontiguousarray(np.stack([synth.synth_lab(rows, cols, i) for i in range(4)]))).cuda().repeat(Bs // 4, 1, 1, 1).contiguous()
+        lab = torch.empty((Bs, rows, cols), dtype=torch.int32, device="cuda")
+        c = Context(local_rank, rows, cols, Bs)
+        ms = timed(torch, lambda: c.slic_labels_dev(imgs, step, nc, lab, stream=cs), 3, stream)
+        out[key] = {"workload": f"Slic::generate_superpixels, {cols}x{rows} Lab, step {step}, nc {nc}, 10 iterations, {Bs} images per call ({name})",
+                    "value": Bs * 1e3 / ms, "unit": "images/s", "roofline": hbm_roofline(Bs * rows * cols * 70, ms)}
+        c.close()
+        del imgs, lab
+    return out
+
+
 def batch1_extras(torch, np, L, local_rank, host, uniq, d_src, d_dst, params):
     """--batch1: BASELINE configs[1] in its PCIe-inclusive forms (never the reported value)."""
     from depth_completion_mt_amd import Context, make_params
@@ -427,6 +472,8 @@ def main():
         }
         if world == 1 and not args.no_configs:
             line["configs"] = other_configs(torch, local_rank, d_src, d_dst, params, stream, args.steps)
+        if world == 1 and not args.no_configs:
+            line["next_rows"] = next_rows(torch, np, local_rank, d_src, d_dst, stream)
         if args.batch1:
             line.update(batch1_extras(torch, np, L, local_rank, host, uniq, d_src, d_dst, params))
         if world == 1 and not args.no_cpu_baseline:
