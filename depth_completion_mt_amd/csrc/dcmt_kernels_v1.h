@@ -155,6 +155,13 @@ __device__ __forceinline__ bool project_point(const ProjMats& M, float x, float 
     return true;
 }
 
+// depth of a point the first pass has already accepted: p.z of project_point, the same operations in the same order
+__device__ __forceinline__ float point_depth(const ProjMats& M, float x, float y, float z)
+{
+    const float tx = dot4_rn(M.T, x, y, z), ty = dot4_rn(M.T + 4, x, y, z), tz = dot4_rn(M.T + 8, x, y, z);
+    return dot4_rn(M.P + 8, tx, ty, tz);
+}
+
 __global__ __launch_bounds__(256)
 void k_project_scatter(const float* __restrict__ pts, const int* __restrict__ offsets, int n_points, int batch,
                        ProjMats M, int* __restrict__ winner, int rows, int cols)
@@ -180,7 +187,8 @@ void k_project_scatter(const float* __restrict__ pts, const int* __restrict__ of
 }
 
 // One thread per PW neighbouring pixels of one frame (grid: x over the frame, y = frame): 8-byte accesses where frames have an
-// even number of pixels.  Most pixels have no point and are a zero; the winners' depths are recomputed from their points.
+// even number of pixels.  Most pixels have no point and are a zero; the winners' depths are recomputed from their points
+// (the depth alone: the pixel is known, so the two divisions and the bounds test of the first pass are not repeated).
 template <int PW>
 __global__ __launch_bounds__(256)
 void k_project_resolve(const float* __restrict__ pts, const int* __restrict__ offsets, ProjMats M,
@@ -199,8 +207,7 @@ void k_project_resolve(const float* __restrict__ pts, const int* __restrict__ of
         o[k] = 0.0f;
         if (w[k] >= 0) {
             const float4 p = *reinterpret_cast<const float4*>(pts + 4 * ((size_t)offsets[f] + w[k]));
-            int u, v;
-            (void)project_point(M, p.x, p.y, p.z, rows, cols, u, v, o[k]);
+            o[k] = point_depth(M, p.x, p.y, p.z);
         }
     }
     if constexpr (PW == 2) *reinterpret_cast<float2*>(sparse + i) = make_float2(o[0], o[1]);

@@ -23,6 +23,7 @@ rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_
 echo "sq done"
 # the label-masked variant (BASELINE configs 2 / 3): kernel stats of both, then per config the two traffic passes and the first SQ pass
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lc -o lc -- python3 $R/tools/time_labeled.py > $OUT/lc.log 2>&1
+python3 $R/tools/time_labeled.py > $OUT/lc_plain.log 2>&1      # the throughput line without the profiler attached
 for c in 2 3; do
 export LC_CONFIG=$c
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/lc${c}_fetch -o f -- python3 $R/tools/time_labeled.py > $OUT/lc${c}_fetch.log 2>&1
@@ -43,8 +44,11 @@ python bench.py --batch1 --no-cpu-baseline --no-configs > $SUM/${TAG}_bench_batc
 f() { find $OUT/$1 -name "*$2" | head -1; }
 cp "$(f stats kernel_stats.csv)" $SUM/${TAG}_kernel_stats.csv
 cp "$(f lc kernel_stats.csv)" $SUM/${TAG}_lc_kernel_stats.csv
-for n in n1 n2 n3 n4; do cp "$(f $n kernel_stats.csv)" $SUM/${TAG}_${n}_kernel_stats.csv; grep -E "frames/s| ms|pairs/s|sweeps/s|per image" $OUT/$n.log > $SUM/${TAG}_${n}_tool_output.txt || true; done
-grep -E "frames/s" $OUT/lc.log > $SUM/${TAG}_lc_tool_output.txt || true
+for n in n1 n2 n3 n4; do cp "$(f $n kernel_stats.csv)" $SUM/${TAG}_${n}_kernel_stats.csv; done
+# the N-row throughput lines without the profiler attached
+python tools/time_norm.py > $SUM/${TAG}_n1_tool_output.txt 2>/dev/null; python tools/time_project.py > $SUM/${TAG}_n2_tool_output.txt 2>/dev/null
+python tools/time_slic.py > $SUM/${TAG}_n3_tool_output.txt 2>/dev/null; python tools/time_stereo.py > $SUM/${TAG}_n4_tool_output.txt 2>/dev/null
+grep -E "frames/s" $OUT/lc_plain.log > $SUM/${TAG}_lc_tool_output.txt || true
 python tools/pmc_traffic.py "$(f fetch counter_collection.csv)" "$(f write counter_collection.csv)" 8 $SUM/${TAG}_traffic.json > /dev/null
 for c in 2 3; do
 python tools/pmc_traffic.py "$(f lc${c}_fetch counter_collection.csv)" "$(f lc${c}_write counter_collection.csv)" 7 $SUM/${TAG}_lc_config${c}_traffic.json > /dev/null
