@@ -137,3 +137,58 @@ def test_mixed_calls_on_one_context_keep_no_state():
                 out = c.stereo_refine_dev(torch.from_numpy(d).cuda(), torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), focal=80.0)
                 torch.cuda.synchronize()
                 assert_bit_equal(out.cpu().numpy(), O.stereo_refine(d, l, r, focal=80.0), what)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_rows_around_the_path_against_oracle(seed):
+    """N2 projection, N3 SLIC, N4 stereo refinement on random sizes, parameters and contents (noise, flat patches with exact
+    ties, few colours, colour weight 1, perturbed calibrations, empty sweeps, disparities that leave the image, 0..6 sweeps)."""
+    import torch
+    from depth_completion_mt_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    rows, cols = int(rng.integers(24, 200)), int(rng.integers(24, 300))
+    step = int(rng.integers(6, min(rows, cols) // 2))
+    nc = int(rng.choice([1, 5, 20, 40, 50, 200]))
+    kind = seed % 4
+    if kind == 0:
+        img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    elif kind == 1:
+        img = np.ascontiguousarray(synth.synth_lab(rows, cols, seed))
+    elif kind == 2:
+        img = np.zeros((rows, cols, 3), np.uint8)
+        for _ in range(6):
+            y, x = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+            img[y:y + int(rng.integers(4, 60)), x:x + int(rng.integers(4, 90))] = rng.integers(0, 256, 3)
+    else:
+        img = (rng.integers(0, 4, (rows, cols, 3)) * 80).astype(np.uint8)
+    with api.Context(0, rows, cols, 2) as c:
+        lab, n, cent = c.slic_labels_dev(torch.from_numpy(img).cuda(), step, nc, return_centers=True)
+        torch.cuda.synchronize()
+        wl, wn, wc = O.slic(img, step, nc, return_centers=True)
+        assert wn == n and np.array_equal(lab.cpu().numpy()[0], wl), ("SLIC", rows, cols, step, nc, kind, int((lab.cpu().numpy()[0] != wl).sum()))
+        ok = ~np.isnan(wc[:, 3])
+        assert np.array_equal(cent.cpu().numpy()[0][ok].view(np.uint64), wc[ok].view(np.uint64)), ("SLIC centres", rows, cols, step, nc)
+        npts = int(rng.integers(0, 40000))
+        pts = synth.synth_points(npts, seed) if npts else np.zeros((0, 4), np.float32)
+        T = (synth.KITTI_T_VELO_TO_CAM + rng.normal(0, 0.01, synth.KITTI_T_VELO_TO_CAM.shape)).astype(np.float32)
+        P = synth.KITTI_P2.copy().astype(np.float32)
+        P[0, 2], P[1, 2] = cols / 2, rows / 2
+        P[0, 0] = P[1, 1] = float(rng.uniform(50, 400))
+        off = torch.tensor([0, npts, npts], dtype=torch.int32, device="cuda")
+        dp = torch.from_numpy(pts).cuda() if npts else torch.zeros((0, 4), dtype=torch.float32, device="cuda")
+        sp = c.project_points_dev(dp, off, T, P, rows, cols).cpu().numpy()
+        assert_bit_equal(sp[0], O.project_points(pts, T, P, rows, cols), f"projection {rows}x{cols}, {npts} points")
+        assert not sp[1].any()
+        l = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        r = np.ascontiguousarray(np.roll(l, -int(rng.integers(0, 9)), axis=1)) if seed % 2 else rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        depth = rng.uniform(0.0, 120.0, (rows, cols)).astype(np.float32)
+        depth[rng.random((rows, cols)) < 0.1] = 0.0
+        if seed % 5 == 0:
+            depth[:, : cols // 3] = rng.uniform(0.01, 0.5, (rows, cols // 3))
+        kw = dict(baseline=float(rng.uniform(0.1, 1.0)), focal=float(rng.uniform(50, 1200)), damp=float(rng.choice([1.0, 50.0, 500.0])),
+                  max_depth=float(rng.choice([50.0, 100.0])))
+        it = int(rng.integers(0, 7))
+        cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()[None]
+        got = c.stereo_refine_dev(cu(depth), cu(l), cu(r), iterations=it, **kw).cpu().numpy()[0]
+        assert_bit_equal(got, O.stereo_refine(depth, l, r, iterations=it, **kw), f"stereo {rows}x{cols}, {it} sweeps, {kw}")
