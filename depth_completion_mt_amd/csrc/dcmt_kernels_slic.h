@@ -124,13 +124,14 @@ __device__ __forceinline__ bool slic_window(const double* C, int step, int rows,
 // registers and adds a run to the table when it ends.  (Several copies of the table, lane & 3: slower -- LDS, occupancy.)
 // Tile height (template parameter TH): as tall as the tile's cells fit -- the staging is paid once per tile and a thread's
 // runs get longer -- 64 rows = 16 per thread for steps from 16 up (at most 7 x 7 staged cells), 32 for steps 11 to 15
-// (9 x 6), 16 for steps 8 to 10 (11 x 5); steps below 8 can exceed 64 cells and take the slow walk.
-constexpr int kSlicTW = 64, kSlicMaxCells = 64;
+// (9 x 6), 16 for the steps below (6: at most 14 x 6 = 84 of the 128 cells a tile may stage).
+constexpr int kSlicTW = 64, kSlicMaxCells = 128;
 __host__ __device__ constexpr int slic_tile_rows(int step) { return step >= 16 ? 64 : (step >= 11 ? 32 : 16); }
 constexpr int kSlicEntries = 128;                                // staged centres per tile, numbered densely (more: slow walk)
 constexpr int kSlicListCap = 9 * kSlicCellCap;
 constexpr int kSlicMaskBits = 32;
 constexpr int kSlicInnerX = 12, kSlicInnerY = 8;                // cells a tile's own pixels may span (more: slow walk)
+static_assert(kSlicMaxCells == 128, "the prefix over the staged cells takes two cells per lane");
 static_assert(kSlicEntries <= 256 && (kSlicEntries & (kSlicEntries - 1)) == 0, "entry numbers are stored as bytes; stale list bytes are masked into range");
 
 template <int TH>
@@ -219,17 +220,22 @@ void k_slic_assign(const uint8_t* __restrict__ lab, const double* __restrict__ c
         s_cnt[c] = min(cell_cnt[cell], kSlicCellCap);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {                        // exclusive prefix of the counts over the (at most 64) staged cells, one wave
-        const int c = threadIdx.x, own = c < ncells ? s_cnt[c] : 0;
-        int inc = own;
+    if (threadIdx.x < 64) {                        // exclusive prefix of the counts over the (at most 128) staged cells, one wave, two cells per lane
+        const int l = threadIdx.x, own0 = l < ncells ? s_cnt[l] : 0, own1 = l + 64 < ncells ? s_cnt[l + 64] : 0;
+        int i0 = own0, i1 = own1;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); inc += c >= d ? o : 0; }
-        s_base[c] = inc - own;
-        if (c == 63) { s_base[64] = inc; if (inc > kSlicEntries) s_slow = 1; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o0 = __shfl_up(i0, d), o1 = __shfl_up(i1, d);
+            i0 += l >= d ? o0 : 0; i1 += l >= d ? o1 : 0;
+        }
+        const int first_half = __shfl(i0, 63);
+        s_base[l] = i0 - own0;
+        s_base[l + 64] = first_half + i1 - own1;
+        if (l == 63) { s_base[128] = first_half + i1; if (first_half + i1 > kSlicEntries) s_slow = 1; }
     }
     __syncthreads();
     if (s_slow) { slow_walk(); return; }                                 // block-uniform
-    const int n_entries = s_base[64];
+    const int n_entries = s_base[kSlicMaxCells];
     for (int t = threadIdx.x; t < ncells * kSlicCellCap; t += 256) {
         const int c = t / kSlicCellCap, k = t % kSlicCellCap;
         if (k < s_cnt[c]) {
