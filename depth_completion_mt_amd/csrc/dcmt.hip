@@ -849,14 +849,19 @@ int dcmt_slic_labels_dev(dcmt_ctx* ctx, const uint8_t* d_lab, int rows, int cols
     hipLaunchKernelGGL(k_slic_init, dim3((n + 63) / 64, batch), dim3(64), 0, st, d_lab, ctx->slic_centers[0], rows, cols, step, n,
                        set_cnt[0], set_list[0], set_ovf[0], cell_px, gx, gy);
     const size_t nb_threads = std::max((size_t)n * batch, n_cnt);
+    // tile height: the tallest the step allows, unless that leaves the GPU short of workgroups (a caller streaming single frames:
+    // 114 tiles of 64 x 64 per 1216 x 352 image for 256 CUs) -- then shorter tiles, more of them, shorter columns per thread
+    int th = slic_tile_rows(cell_px);
+    { const char* e = std::getenv("DCMT_SLIC_TH"); if (e && (std::atoi(e) == 16 || std::atoi(e) == 32 || std::atoi(e) == 64) && std::atoi(e) <= th) th = std::atoi(e);
+      else while (th > 16 && (size_t)((cols + kSlicTW - 1) / kSlicTW) * ((rows + th - 1) / th) * batch < 1024) th /= 2; }
     for (int it = 0; it < 10; ++it) {                                                           // NR_ITERATIONS (slic.h:20)
         double* cur = ctx->slic_centers[it & 1];
         double* nxt = ctx->slic_centers[(it + 1) & 1];
         const int a = it & 1, b = a ^ 1;
-        if (slic_tile_rows(cell_px) == 64)
+        if (th == 64)
             hipLaunchKernelGGL(k_slic_assign<64>, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + 63) / 64, batch), dim3(256), 0, st, d_lab, cur,
                                set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
-        else if (slic_tile_rows(cell_px) == 32)
+        else if (th == 32)
             hipLaunchKernelGGL(k_slic_assign<32>, dim3((cols + kSlicTW - 1) / kSlicTW, (rows + 31) / 32, batch), dim3(256), 0, st, d_lab, cur,
                                set_cnt[a], set_list[a], set_ovf[a], d_labels, ctx->slic_sums, rows, cols, step, nc, n, gx, gy, cell_px);
         else
