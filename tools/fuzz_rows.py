@@ -14,4 +14,4 @@ for seed in range(first, first + n):
     except AssertionError as e:
         bad += 1
         print("SEED", seed, str(e)[:300])
-print("done, failures:", bad)
+print(f"done, {n} cases (seeds {first}..{first + n - 1}), failures: {bad}")
