@@ -212,6 +212,12 @@ def next_rows(torch, np, local_rank, d_src, d_dst, stream):
     ms = timed(torch, lambda: c.complete_dev(d_src, d_dst, pn, stream=cs), 10, stream)
     out["N1_normalize_complete"] = {"workload": f"cv::normalize(0, 80) + img_completion, {COLS}x{ROWS}, {B} frames per step (SL/main_sl.cpp:370)",
                                     "value": B * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(B * BYTES_PER_FRAME, ms)}
+    # the KITTI uint16 payload as input (LO/main.cpp:75-82: imread(ANYDEPTH) + convertTo(CV_32F, 1/256) fused into the first load): 6 B/px
+    u16 = torch.round(d_src * 256.0).to(torch.int32).to(torch.int16)          # the synthetic depths are multiples of 1/256 below 128 m
+    ms = timed(torch, lambda: c.complete_u16_dev(u16, 1.0 / 256.0, d_dst, make_params(), stream=cs), 10, stream)
+    out["N1_uint16_ingest_complete"] = {"workload": f"uint16 depth payload -> metres -> img_completion, {COLS}x{ROWS}, {B} frames per step (LO/main.cpp:75-93)",
+                                        "value": B * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(B * ROWS * COLS * 6, ms)}
+    del u16
     c.close()
     rows, cols, Bp, N = 375, 1242, 256, 120000
     pts = torch.from_numpy(np.concatenate([synth.synth_points(N, i) for i in range(8)])).cuda().repeat(Bp // 8, 1).contiguous()
