@@ -169,6 +169,28 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
     out["4_per_gpu_share"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {b128} frames per step (the per-GPU shard of 1024 frames on 8 GPUs)",
                               "value": b128 * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(b128 * BYTES_PER_FRAME, ms)}
     c4.close()
+    # the same 1024-frame step as four parts of 256 frames in flight on four streams, after the GPU has been busy for a while
+    if B >= 1024:
+        n4 = B // 4
+        cs = [Context(local_rank, ROWS, COLS, n4) for _ in range(4)]
+        ss = [torch.cuda.Stream() for _ in range(4)]
+        def four():
+            for k in range(4):
+                cs[k].complete_dev(d_src[k * n4:(k + 1) * n4], d_dst[k * n4:(k + 1) * n4], params, stream=ss[k].cuda_stream)
+        for _ in range(40):
+            four()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        for _ in range(60):
+            four()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 60 * 1e3
+        out["4_in_flight"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {4 * n4} frames per step as 4 contexts x {n4} frames on 4 streams, never joined "
+                                          "(k_pre of one part beside k_fp_s of another); 40 untimed + 60 timed steps, host clock around a device synchronise",
+                              "value": 4 * n4 * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(4 * n4 * BYTES_PER_FRAME, ms)}
+        for c in cs:
+            c.close()
     # [2] DC_lidar_camera 352x1216 + int32 label plane (~1200 superpixels, main_lc.cpp:188-197); [3] DC_stereo_lidar 375x1242 (~100, main_sl.cpp:443)
     for key, rows, cols, nt, name in (("2", 352, 1216, 1200, "DC_lidar_camera"), ("3", 375, 1242, 100, "DC_stereo_lidar")):
         Bl = 256
@@ -353,6 +375,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank owns --batch frames per step")
     ap.add_argument("--batch", type=int, default=1024, help="--weak: frames per GPU per step")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames per GPU (tiled to the rank's frame count)")
+    ap.add_argument("--parts", type=int, default=1,
+                    help="contexts (one stream each) a rank's frames are spread over, never joined inside the timed region (default 1: one call "
+                         "per step; configs['4_in_flight'] reports four)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the sub-results for BASELINE configs [1] [2] [3]")
     ap.add_argument("--batch1", action="store_true", help="also time the PCIe-inclusive forms of configs[1]")
@@ -392,37 +417,56 @@ def main():
     reps = (B + uniq - 1) // uniq
     d_src = d_uniq.repeat(reps, 1, 1)[:B].contiguous()
     d_dst = torch.empty_like(d_src)
-    ctx = Context(local_rank, ROWS, COLS, B)
     params = make_params()                              # the reference's literals; 1 speculative loop application
     stream = torch.cuda.current_stream()
+    # --parts P: frames are independent, so a rank's frames may go to P contexts, one stream each, with nothing joining them inside
+    # the timed region: k_pre (bound by memory) of one part then runs beside k_fp_s (bound by VALU issue) of another -- what a caller
+    # streaming batches through the library has with several calls in flight.  Worth +5..13 % at 1024 frames in parts of 256 once
+    # the GPU has been busy for some tens of milliseconds, nothing in a 20-step run from a cold start (tools/time_two_streams.py,
+    # DESIGN.md section 7), so the headline stays one call per step and configs["4_in_flight"] reports the other.
+    from depth_completion_mt_amd.sharding import shard_range
+    parts = max(1, min(args.parts, B))
+    bounds = [shard_range(B, k, parts) for k in range(parts)]
+    ctxs = [Context(local_rank, ROWS, COLS, e - b) for b, e in bounds]
+    streams = [torch.cuda.Stream() for _ in range(parts)] if parts > 1 else [stream]
 
     def step():
-        ctx.complete_dev(d_src, d_dst, params, stream=stream.cuda_stream)
+        for c, (b, e), s_ in zip(ctxs, bounds, streams):
+            c.complete_dev(d_src[b:e], d_dst[b:e], params, stream=s_.cuda_stream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     t0 = time.perf_counter()
-    ev0.record(stream)
+    for e_, s_ in zip(ev0, streams):
+        e_.record(s_)
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
+    for e_, s_ in zip(ev1, streams):
+        e_.record(s_)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream
+    # HIP events on the launch streams: from the first stream's start to the last stream's end
+    gpu_ms_per_step = max(a.elapsed_time(b) for a in ev0 for b in ev1) / args.steps
 
     # every frame must have converged inside the timed configuration (no skipped work).  The status goes through the same
     # all-reduce as the times, so that a failing rank cannot leave the others waiting in a collective.
-    iters, st = ctx.last_fill_iters(B)
+    iters, st = [], L.OK
+    for c, (b, e) in zip(ctxs, bounds):
+        it_k, st_k = c.last_fill_iters(e - b)
+        iters += list(it_k)
+        st = st if st_k == L.OK else st_k
     failed, elapsed, gpu_ms_per_step = all_reduce_max(dist, [0.0 if st == L.OK else 1.0, elapsed, gpu_ms_per_step], device="cuda")
     if failed:
         if dist is not None:
@@ -430,18 +474,26 @@ def main():
         raise SystemExit("a frame needed more hole-closure applications than were enqueued: result invalid")
 
     if rank == 0:
-        # live per-kernel split: one more (untimed) step with the library's own events around its kernel groups
+        # the same frames through ONE context on one stream (what a single call gives), and its live per-kernel split: untimed
+        # steps with the library's own events around its kernel groups
+        ctx = Context(local_rank, ROWS, COLS, B)
+        one_ms = timed(torch, lambda: ctx.complete_dev(d_src, d_dst, params, stream=stream.cuda_stream), args.steps, stream)
         ctx.set_kernel_timing(True)
         kt = [0.0, 0.0, 0.0, 0.0]
         nk = 5
         for _ in range(nk):
-            step()
+            ctx.complete_dev(d_src, d_dst, params, stream=stream.cuda_stream)
             t = ctx.last_kernel_times()
             kt = [a + b / nk for a, b in zip(kt, (t["front"], t["k_pre"], t["k_fp_s"], t["behind"]))]
         ctx.set_kernel_timing(False)
+        ctx.close()
         roof = hbm_roofline(B * BYTES_PER_FRAME, gpu_ms_per_step)
-        roof["kernel"] = ("whole cascade per step = k_pre_p + k_fp_s (+ 3 redo launches that return at once), HIP events around the K timed steps "
-                          "on the launch stream; per_kernel: the library's own events (dcmt_set_kernel_timing) in 5 extra steps; rocprofv3 averages in profiles/")
+        roof["kernel"] = ("whole cascade per step = k_pre_p + k_fp_s (+ 3 redo launches that return at once) of every part, HIP events on the launch streams "
+                          "around the K timed steps (first start to last end); with more than one part the kernels of different parts overlap, so the per-kernel "
+                          "durations of a profile add up to more than the step; per_kernel and single_context: the same frames through ONE context on one stream "
+                          "(the library's own events, dcmt_set_kernel_timing, 5 extra steps); rocprofv3 averages of that single-context step in profiles/")
+        roof["single_context"] = dict(hbm_roofline(B * BYTES_PER_FRAME, one_ms), value=B * 1e3 / one_ms, unit="frames/s",
+                                      note="one dcmt_complete_f32_dev call per step on one stream: the kernels run one after the other")
         roof["per_kernel"] = {"k_pre": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
                               "k_fp_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="reads X6, writes the dense frame"),
                               "redo_launches_ms": kt[3]}
@@ -472,7 +524,9 @@ def main():
                                     + (f"= {args.batch} per GPU (weak scaling)" if args.weak else
                                        f"sharded per frame over {world} GPU(s) = {B} per GPU (BASELINE configs[4]; strong scaling)")),
                        "total_frames_per_step": total, "frames_per_gpu_per_step": B, "rows": ROWS, "cols": COLS, "k0": "as_compiled", "blur": "gaussian",
-                       "sharding": "per-frame, no collective"},
+                       "sharding": "per-frame, no collective",
+                       "contexts_per_gpu": parts, "frames_per_context": [e - b for b, e in bounds],
+                       "in_flight": "one call per context and step, one stream per context, joined only at the ends of the timed region"},
             "roofline": roof,
             "fill_iters_max": max(iters),
         }
@@ -485,7 +539,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))   # the box's CPU share for one GPU is 16
         print(json.dumps(line))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
