@@ -19,6 +19,8 @@
 #include "dcmt_kernels_v1.h"
 #include "dcmt_kernels_fused.h"
 #include "dcmt_kernels_pair.h"
+#include "dcmt_kernels_fp_pair.h"
+#include "dcmt_kernels_fp_q16.h"
 #include "dcmt_kernels_slic.h"
 
 using namespace dcmt;
@@ -58,6 +60,8 @@ struct dcmt_ctx {
     int top_table = 1;                // k_pre leaves the extension zones of X6 unwritten, k_fp_s clamps its rows and starts below the top one; env DCMT_TOP_TABLE=0 disables
     int pair = 1;                     // two columns per lane in H2..H6 (k_pre_p) where the width is even; env DCMT_PAIR=0 keeps k_pre_s
     int bands = 0;                    // row bands per strip in k_pre_p (0 = by batch size); env DCMT_BANDS
+    int fp_pair = 0;                  // env DCMT_FP_PAIR=1: two columns per lane in H7..H11 (k_fp_p: 8 % fewer VALU instructions, but its ~200 VGPRs leave 2 waves per SIMD and it is slower)
+    int fp_q16 = 0;                   // env DCMT_FP_Q16=1: H7..H11 on 16-bit codes (k_fp_q) -- the caller vouches that every frame is a multiple of 1/256 m
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
@@ -144,6 +148,11 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
 dim3 wave_grid(int strips, int batch, int xcd_map)
 {
     return dim3(xcd_map ? 8 * (((batch / 8) * strips + 3) / 4) : (batch * strips + 3) / 4);
+}
+
+dim3 wave_grid_n(int strips, int batch, int xcd_map, int wpb)
+{
+    return dim3(xcd_map ? 8 * (((batch / 8) * strips + wpb - 1) / wpb) : (batch * strips + wpb - 1) / wpb);
 }
 
 dim3 tile_grid(int rows, int cols, int batch) { return dim3((cols + TW - 1) / TW, (rows + TH - 1) / TH, batch); }
@@ -287,7 +296,22 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
             // k_fp_s deals (frame, strip) pairs to waves in one flat sequence (per XCD with the XCD map): no half-empty workgroups
             const dim3 fpg = wave_grid(pstrips, nb, xm);
-            if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+            // two columns per lane (k_fp_p) wherever a lane's 8-byte stores are aligned: even width, 8-byte aligned frames
+            const bool fpp = ctx->fp_pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0);
+            const bool fpq = ctx->fp_q16 && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0) && Q16::params_ok(p->max_depth, p->valid_thresh);
+            if (fpq) {
+                const int qstrips = (cols + FpP::VW - 1) / FpP::VW;
+                const dim3 qg = wave_grid(qstrips, nb, xm);
+                if (bl) hipLaunchKernelGGL((k_fp_q<true, false>), qg, b256, 0, st, (const void*)x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+                else    hipLaunchKernelGGL((k_fp_q<false, false>), qg, b256, 0, st, (const void*)x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+            }
+            else if (fpp) {
+                const int qstrips = (cols + FpP::VW - 1) / FpP::VW;
+                const dim3 qg = wave_grid_n(qstrips, nb, xm, FpP::WPB), qb(64 * FpP::WPB);
+                if (bl) hipLaunchKernelGGL((k_fp_p<true>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+                else    hipLaunchKernelGGL((k_fp_p<false>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+            }
+            else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
             else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
             DCMT_HIP(ctx, hipGetLastError());
             stamp(3);
@@ -656,6 +680,8 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_XCD_MAP"); if (e) ctx->xcd_map = std::atoi(e); }
     { const char* e = std::getenv("DCMT_WIDE"); if (e) ctx->wide = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_FP_PAIR"); if (e) ctx->fp_pair = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_FP_Q16"); if (e) ctx->fp_q16 = std::atoi(e); }
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }

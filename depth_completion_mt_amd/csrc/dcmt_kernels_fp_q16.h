@@ -1,0 +1,333 @@
+// dcmt_kernels_fp_q16.h -- k_fp_q: H7, H9..H11 for frames whose depths are multiples of 1/256 m (the KITTI depth format: every
+// frame the reference's lidar-only and lidar-camera callers feed the path is a uint16 PNG payload / 256, LO/main.cpp:75-82).
+//
+// H2..H9 only ever SELECT values (max, min, median), so on such a frame every value of X2..X9 is one of
+//     j / 256,   j in [-39935, 25600]        (an empty pixel k / 256 with k < 26, an inverted depth (25600 - k) / 256, or the 100
+//                                             of a column without valid pixels, LO :110)
+// -- with max_depth = 100 and thr = 0.1 (the reference's constants; other values run the f32 kernels).  code = j + 39935 is a
+// 16-bit unsigned integer, the map is strictly increasing, so maxima / minima / medians of codes are the codes of the f32
+// results, and a hole (x < 0.1f) is code <= 39960.  Two adjacent columns then fit ONE register (low half = column 2l, high
+// half = column 2l + 1) and v_pk_max_u16 / v_pk_min_u16 work on both at the price of one v_max_f32: what k_fp_p
+// (dcmt_kernels_fp_pair.h) gains from two columns per lane, without its doubled register state -- this kernel keeps k_fp_s's
+// occupancy.  gfx950 has no packed three-input min / max / med3, so the median runs the two-input networks of
+// median_shared_nets.h: 18 + (26 + 36) / 2 + 10 = 59 packed instructions per row for two columns (k_fp_s: 38.5 per column), and
+// the five sorted neighbours of BOTH columns are one DPP shift each way plus two v_alignbit (4 instead of 2 x 4 moves).
+// The median is converted back (code -> f32 is exact: one v_cvt and one fused multiply-add) and the Gaussian, the masked select
+// and the final invert are the f32 code of k_fp_p (PostPipeP::after_median), so the output is bit-identical to k_fp_s's.
+//
+// Fill: the vertical 31-maximum runs packed (6 two-input instructions for 128 columns); the horizontal one, on rows that have
+// a hole, unpacks the two halves and is k_fp_p's scheme on unsigned integers (0 is the neutral element; register B holds the
+// 30 halo columns unpacked, one per lane).
+//
+// X6U16 = false: X6 arrives as f32 (k_pre_p / k_pre_s as they are) and is converted while loading (exact for a conforming
+// frame).  What a frame that does NOT conform produces is garbage of the right shape; the caller must only use this kernel on
+// frames it knows to conform (dcmt.hip: the uint16 entry point with scale 1/256, or frames the conformance pass has cleared).
+#pragma once
+
+#include "dcmt_kernels_fp_pair.h"
+
+namespace dcmt {
+
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned qmax(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b)));
+}
+__device__ __forceinline__ unsigned qmin(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b)));
+}
+__device__ __forceinline__ unsigned umax2(unsigned a, unsigned b) { return a > b ? a : b; }
+
+struct Q16 {
+    static constexpr int OFFSET = 39935;                         // code = 256 x + OFFSET
+    static constexpr unsigned HOLE_MAX = 25 + OFFSET;            // x < 0.1f  <=>  256 x <= 25  <=>  code <= HOLE_MAX
+    static constexpr unsigned HOLE_MAX_HI = (HOLE_MAX << 16) | 0xffffu;   // the same test on the high half of a packed pair
+    __device__ static __forceinline__ unsigned code(float x) { return (unsigned)((int)__fmul_rn(x, 256.0f) + OFFSET); }
+    __device__ static __forceinline__ float value(unsigned c) { return __builtin_fmaf((float)c, 0.00390625f, -155.99609375f); }   // (c - 39935) / 256, exact
+    __host__ __device__ static bool params_ok(float max_depth, float thr) { return max_depth == 100.0f && thr == 0.1f; }
+};
+
+// shifts with 0 in the lane without a source (unsigned codes: 0 is the neutral element of max)
+__device__ __forceinline__ unsigned u_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned u_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned u_row_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned u_row_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned u_row_ror8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }
+__device__ __forceinline__ void u_row_scans4(unsigned a, unsigned b, unsigned& pa, unsigned& sa, unsigned& pb, unsigned& sb)
+{
+    pa = a; sa = a; pb = b; sb = b;
+#define DCMT_U4(N) "v_max_u32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                   "v_max_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                   "v_max_u32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                   "v_max_u32_dpp %3, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" DCMT_U4(1) DCMT_U4(2) DCMT_U4(4) DCMT_U4(8) : "+v"(pa), "+v"(sa), "+v"(pb), "+v"(sb));
+#undef DCMT_U4
+}
+
+// The exact 5x5 median of dcmt_median.h on packed pairs: the two-input networks of median_shared_nets.h (the three-input
+// forms need v_min3 / v_max3 / v_med3, which have no packed 16-bit version).
+#define DCMT_QCX(a, b)   { const unsigned lo_ = qmin(v[a], v[b]); v[b] = qmax(v[a], v[b]); v[a] = lo_; }
+#define DCMT_QCMIN(a, b) { v[a] = qmin(v[a], v[b]); }
+#define DCMT_QCMAX(a, b) { v[b] = qmax(v[a], v[b]); }
+__device__ __forceinline__ void q_sort5(unsigned (&v)[5]) { DCMT_SORT5_NET(DCMT_QCX, DCMT_QCMIN, DCMT_QCMAX) }
+__device__ __forceinline__ void q_merge55(const unsigned (&a)[5], const unsigned (&b)[5], unsigned (&P)[10])
+{
+    constexpr int out[10] = DCMT_MERGE55_OUT;
+    unsigned v[10];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { v[k] = a[k]; v[5 + k] = b[k]; }
+    DCMT_MERGE55_NET(DCMT_QCX, DCMT_QCMIN, DCMT_QCMAX)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) P[k] = v[out[k]];
+}
+__device__ __forceinline__ void q_mid20(const unsigned (&pa)[10], const unsigned (&pb)[10], unsigned (&C)[6])
+{
+    constexpr int out[6] = DCMT_MID20_OUT;
+    unsigned v[20];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { v[k] = pa[k]; v[10 + k] = pb[k]; }
+    DCMT_MID20_NET(DCMT_QCX, DCMT_QCMIN, DCMT_QCMAX)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = v[out[k]];
+}
+#undef DCMT_QCX
+#undef DCMT_QCMIN
+#undef DCMT_QCMAX
+// 6th smallest of sorted C (6) u sorted a (5): min(C5, max(a0,C4), max(a1,C3), max(a2,C2), max(a3,C1), max(a4,C0))
+__device__ __forceinline__ unsigned q_final6(const unsigned (&C)[6], const unsigned (&a)[5])
+{
+    unsigned r = C[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r = qmin(r, qmax(a[i], C[4 - i]));
+    return r;
+}
+struct MedianColumnQ {       // MedianColumn (dcmt_median.h) on packed pairs
+    unsigned SE[4][5], SO[5], P[2][10], C[6];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SE[q][k] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) SO[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { P[0][k] = 0; P[1][k] = 0; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = 0;
+    }
+    template <int PP>
+    __device__ __forceinline__ unsigned step(const unsigned (&s)[5])
+    {
+        unsigned m;
+        if constexpr ((PP & 1) == 0) {
+            constexpr int qs = (PP >> 1) & 3;
+            q_merge55(SO, s, P[(PP >> 1) & 1]);
+            q_mid20(P[((PP >> 1) + 1) & 1], P[(PP >> 1) & 1], C);
+            m = q_final6(C, SE[(qs + 2) & 3]);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SE[qs][k] = s[k];
+        } else {
+            m = q_final6(C, s);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) SO[k] = s[k];
+        }
+        return m;
+    }
+};
+
+template <bool BLUR, bool X6U16>
+__global__ __launch_bounds__(256)
+void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restrict__ counters,
+            int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb,
+            int tbands)
+{
+    // per wave: centre values and A's 18-row maxima (packed pairs, one word per lane), B's 18-row maxima
+    __shared__ unsigned s_delay[4][16 * (64 + 64 + 32)];            // 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int f, strip;
+    if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;
+    int* cnt = frame_counters(counters, f);
+    const size_t fo = (size_t)f * rows_all * cols;
+    const int gx0 = strip * FpP::VW - FpP::H;
+    const int gxe = gx0 + 2 * lane;
+    // B, one column per lane, unpacked (k_fp_p's layout).  The dead lanes 16..47 (two whole DPP rows) shadow lane 0: same column,
+    // same values, same delay-line word -- their stores write what lane 0 writes
+    const int gxb = lane < 8 ? gx0 + 128 + 2 * lane : (lane < 16 ? gx0 + 128 + 2 * (lane - 8) + 1 :
+                    (lane >= 56 ? gx0 - 16 + 2 * (lane - 56) : (lane >= 48 ? gx0 - 16 + 2 * (lane - 48) + 1 : gx0 + 128)));
+    const int gxec = min(max(gxe, 0), cols - 2), gxoc = gxec + 1, gxbc = min(max(gxb, 0), cols - 1);
+    int tie = 0, tio = 0, tib = 0, bie = rows_all - 1, bio = rows_all - 1, bib = rows_all - 1, V = 0;
+    if (tb) {
+        table_rows(tb, f, cols, tbands, rows_all, gxec, tie, bie);
+        table_rows(tb, f, cols, tbands, rows_all, gxoc, tio, bio);
+        table_rows(tb, f, cols, tbands, rows_all, gxbc, tib, bib);
+        V = __builtin_amdgcn_readfirstlane(max(wave_min_i(min(min(tie, tio), tib)) - 8, 0));
+    }
+    const int rows = rows_all - V;
+    constexpr unsigned EB = X6U16 ? 2u : 4u;                         // bytes per X6 element
+    FrameBuf sf;
+    sf.init(reinterpret_cast<const float*>(static_cast<const char*>(x6_) + fo * EB), (size_t)rows_all * cols * EB / 4);
+    const unsigned rowb = EB * (unsigned)cols;
+    const unsigned sbe = EB * (unsigned)gxec + (unsigned)V * rowb, sbo = sbe + EB, sbb = EB * (unsigned)gxbc + (unsigned)V * rowb;
+    const unsigned fle = EB * (unsigned)gxec + (unsigned)max(tie, V) * rowb, cee = EB * (unsigned)gxec + (unsigned)max(bie, V) * rowb;
+    const unsigned flo = EB * (unsigned)gxoc + (unsigned)max(tio, V) * rowb, ceo = EB * (unsigned)gxoc + (unsigned)max(bio, V) * rowb;
+    const unsigned flb = EB * (unsigned)gxbc + (unsigned)max(tib, V) * rowb, ceb = EB * (unsigned)gxbc + (unsigned)max(bib, V) * rowb;
+    auto clamp3 = [](unsigned a, unsigned lo, unsigned hi) -> unsigned { unsigned r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi)); return r; };
+    // one column's code at a (clamped) byte offset
+    auto ld_code = [&](unsigned off) -> unsigned {
+        if constexpr (X6U16) return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(sf.rs, off, 0, 0);
+        else return Q16::code(sf.ld_at(off));
+    };
+    struct Raw { unsigned e, o, b; };
+    auto ld_row = [&](int row) -> Raw {                              // row relative to V, already clamped to [0, rows)
+        return {ld_code(clamp3(sbe + (unsigned)row * rowb, fle, cee)), ld_code(clamp3(sbo + (unsigned)row * rowb, flo, ceo)),
+                ld_code(clamp3(sbb + (unsigned)row * rowb, flb, ceb))};
+    };
+    auto pack = [](unsigned e, unsigned o) -> unsigned { return e | (o << 16); };
+    const bool outside = gxe < 0 || gxe >= cols;
+    const bool own = !outside && 2 * lane >= FpP::H && 2 * lane < 128 - FpP::H;
+    const unsigned long long own_mask = __ballot(own);
+    const bool edge_strip = gx0 < 0 || gx0 + 127 >= cols;
+    const int rep_l = min(max((0 - gx0) >> 1, 0), 63), rep_r = min(max((cols - 2 - gx0) >> 1, 0), 63);
+    const int a_m8 = ((lane - 8) & 63) * 4, a_p8 = ((lane + 8) & 63) * 4;
+    const bool b_lo = lane < 8, b_hi = lane >= 56;
+    unsigned* sd = s_delay[wave];
+    unsigned (*dl_c)[64] = reinterpret_cast<unsigned (*)[64]>(sd);
+    unsigned (*dl_a)[64] = reinterpret_cast<unsigned (*)[64]>(sd + 16 * 64);
+    unsigned (*dl_b)[32] = reinterpret_cast<unsigned (*)[32]>(sd + 16 * 128);
+    const int lb = lane < 16 ? lane : (lane >= 48 ? lane - 32 : 0);
+
+    PostPipeP<BLUR> pipe;                                            // only its after_median() half is used
+    pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
+    MedianColumnQ mc;
+    mc.init();
+
+    const bool warm = V > 0;
+    unsigned xa0 = 0, xb0 = 0;                                       // cold start: 0 is the neutral element
+    if (warm) { const Raw r = ld_row(0); xa0 = pack(r.e, r.o); xb0 = r.b; }
+    unsigned PFA[16], PFB[16], W2A[16], W6A[16], W2B[16], W6B[16], DL[8];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { PFA[q] = PFB[q] = 0; W2A[q] = W6A[q] = xa0; W2B[q] = W6B[q] = xb0; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) DL[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; dl_b[q][lb] = xb0; }
+    constexpr int PFD = 6;
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) {
+        const Raw r = ld_row(min(max(q + (warm ? 16 : 0) - 15, 0), rows - 1));
+        PFA[q] = pack(r.e, r.o); PFB[q] = r.b;
+    }
+    unsigned vpa = xa0, vpb = xb0, x7_prev = xa0;
+    int before = 0, after = 0;
+    unsigned pend_v = xa0, pend_f1 = 0, pend_f2 = 0, pend_f3 = 0, pend_f4 = 0;
+    unsigned long long pend_hme = 0, pend_hmo = 0;
+    unsigned nxt_c = xa0, nxt_a = xa0, nxt_b = xb0;
+
+    // the fill front end of step t: returns X7 (packed codes) of image row t - 31
+    auto fill_step = [&](auto P_, int t) -> unsigned {
+        constexpr int p = decltype(P_)::value;
+        const unsigned xa = PFA[p], xb = PFB[p];
+        {
+            const Raw r = ld_row(min(max(t + PFD - 15, 0), rows - 1));
+            PFA[(p + PFD) & 15] = pack(r.e, r.o); PFB[(p + PFD) & 15] = r.b;
+        }
+        const int o = t - 31;
+        unsigned x7 = pend_v;
+        if ((pend_hme | pend_hmo) != 0ull) {
+            const unsigned d = umax2(pend_f1, pend_f2) | (umax2(pend_f3, pend_f4) << 16);
+            const bool he = __builtin_amdgcn_inverse_ballot_w64(pend_hme), ho = __builtin_amdgcn_inverse_ballot_w64(pend_hmo);
+            const unsigned m = (he ? 0xffffu : 0u) | (ho ? 0xffff0000u : 0u);
+            x7 = (d & m) | (pend_v & ~m);
+            if ((unsigned)o < (unsigned)rows) {
+                before += __builtin_popcountll(pend_hme & own_mask) + __builtin_popcountll(pend_hmo & own_mask);
+                after += __builtin_popcountll(__builtin_amdgcn_ballot_w64((x7 << 16) <= Q16::HOLE_MAX_HI) & own_mask) +
+                         __builtin_popcountll(__builtin_amdgcn_ballot_w64(x7 <= Q16::HOLE_MAX_HI) & own_mask);
+            }
+        }
+        if (edge_strip) {                                           // out-of-image columns replicate the edge column
+            const unsigned l0 = (unsigned)__shfl((int)x7, rep_l, 64), r0 = (unsigned)__shfl((int)x7, rep_r, 64);
+            if (gxe < 0) x7 = (l0 & 0xffffu) | (l0 << 16);
+            if (gxe >= cols) x7 = (r0 >> 16) | (r0 & 0xffff0000u);
+        }
+        if (o >= rows) { asm volatile("" ::); x7 = x7_prev; }
+        x7_prev = x7;
+        // vertical 31-max: A packed (two-input instructions), B unpacked
+        const unsigned w2a = qmax(xa, vpa), w2b = umax2(xb, vpb);
+        vpa = xa; vpb = xb;
+        W2A[p] = w2a; W2B[p] = w2b;
+        const unsigned w6a = qmax(qmax(w2a, W2A[(p + 14) & 15]), W2A[(p + 12) & 15]);
+        const unsigned w6b = umax2(umax2(w2b, W2B[(p + 14) & 15]), W2B[(p + 12) & 15]);
+        W6A[p] = w6a; W6B[p] = w6b;
+        const unsigned w18a = qmax(qmax(w6a, W6A[(p + 10) & 15]), W6A[(p + 4) & 15]);
+        const unsigned w18b = umax2(umax2(w6b, W6B[(p + 10) & 15]), W6B[(p + 4) & 15]);
+        const unsigned v = nxt_c, w18a_old = nxt_a, w18b_old = nxt_b;
+        nxt_c = dl_c[(p + 2) & 15][lane];
+        nxt_a = dl_a[(p + 4) & 15][lane];
+        nxt_b = dl_b[(p + 4) & 15][lb];
+        dl_c[p][lane] = xa;
+        dl_a[p][lane] = w18a;
+        dl_b[p][lb] = w18b;
+        const unsigned w31a = qmax(w18a, w18a_old), w31b = umax2(w18b, w18b_old);
+        const unsigned long long vme = __builtin_amdgcn_ballot_w64((v << 16) <= Q16::HOLE_MAX_HI), vmo = __builtin_amdgcn_ballot_w64(v <= Q16::HOLE_MAX_HI);
+        if ((vme | vmo) != 0ull) {
+            // horizontal 31-max: k_fp_p's scheme on the unpacked halves
+            const unsigned e = w31a & 0xffffu, od = w31a >> 16;
+            const unsigned bo = u_row_ror8(w31b);
+            unsigned pa, sa, pb, sb;
+            u_row_scans4(umax2(e, od), umax2(w31b, bo), pa, sa, pb, sb);
+            const unsigned pxa = u_row_shr1(pa), sxa = u_row_shl1(sa), pxb = u_row_shr1(pb), sxb = u_row_shl1(sb);
+            const unsigned sx = b_hi ? sxb : sxa, so = umax2(b_hi ? bo : od, sx);
+            const unsigned px = b_lo ? pxb : pxa, pe = umax2(b_lo ? w31b : e, px);
+            pend_f1 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)so);
+            pend_f2 = (unsigned)__builtin_amdgcn_ds_bpermute(a_p8, (int)px);
+            pend_f3 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)sx);
+            pend_f4 = (unsigned)__builtin_amdgcn_ds_bpermute(a_p8, (int)pe);
+        }
+        pend_v = v;
+        pend_hme = vme; pend_hmo = vmo;
+        return x7;
+    };
+    // post step u: the median of image row u - 4 on packed pairs, then PostPipeP's f32 tail
+    auto post_step = [&](auto PP_, unsigned x, int u) {
+        constexpr int PP = decltype(PP_)::value;
+        const unsigned rl = u_left(x), rr = u_right(x);              // columns 2l-2, 2l-1 | 2l+2, 2l+3
+        unsigned s[5] = {rl, __builtin_amdgcn_alignbit(x, rl, 16), x, __builtin_amdgcn_alignbit(rr, x, 16), rr};
+        q_sort5(s);
+        const unsigned m = mc.template step<PP>(s);
+        pipe.template after_median<PP>(Q16::value(m & 0xffffu), Q16::value(m >> 16), u);
+    };
+
+    for (int t0 = warm ? 16 : 0; t0 < FpP::LAG; t0 += 16) {
+        static_for<0, 16>([&](auto P_) {
+            constexpr int p = decltype(P_)::value;
+            DL[p & 7] = fill_step(P_, t0 + p);
+        });
+    }
+    DL[5] = DL[6] = DL[7];
+    const int nsteps = rows + 38;
+    for (int t0 = FpP::LAG; t0 < nsteps; t0 += 16) {
+        static_for<0, 16>([&](auto P_) {
+            constexpr int p = decltype(P_)::value;
+            const int t = t0 + p, u = t - FpP::LAG;
+            DL[p & 7] = fill_step(P_, t);
+            post_step(std::integral_constant<int, (p & 7)>{}, DL[(p + 5) & 7], u);
+            if constexpr (p == 6) {
+                if (t0 == FpP::LAG && V > 0) {
+                    FrameBuf top;
+                    top.init(dst + fo, (size_t)V * cols);
+                    const unsigned tbo = pipe.outlane ? pipe.ob : kDropOffset;
+                    for (int r = 0; r < V; ++r) st2(top, tbo, r, cols, pipe.last_out);
+                }
+            }
+        });
+    }
+    if (lane == 0) {
+        if (before) atomicAdd(&cnt[0], before);
+        if (after) atomicAdd(&cnt[1], after);
+    }
+}
+
+}  // namespace dcmt

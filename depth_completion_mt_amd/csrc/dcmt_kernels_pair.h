@@ -321,7 +321,10 @@ __device__ __forceinline__ void label_pipeline_p(const FrameBuf& sb, const Frame
 #pragma unroll
     for (int q = 0; q < 8; ++q) { PF[q] = Z2; H4[q] = h4i; HE[q] = hei; XR[q] = {s0i, s0i}; A3[q] = {s0i, s0i}; OX[q] = s0i; S1E[q] = s0i; PLe[q] = PLo[q] = LBe[q] = LBo[q] = -1; }
     const int rs = w ? y0 : y0 - 6;                // image row of step 0
-    constexpr int PFD = 4;
+#ifndef DCMT_LABEL_PFD
+#define DCMT_LABEL_PFD 4
+#endif
+    constexpr int PFD = DCMT_LABEL_PFD;
     // INTERIOR: wa = byte offset of (row i - 6, this lane's columns), the row written in step i; the loads reach ahead of it
     // through the scalar offset.  (rs >= 10, so wa never goes below the frame.)
     unsigned wa = gb + rowb * (unsigned)(rs - 6);
@@ -386,8 +389,14 @@ __device__ __forceinline__ void label_pipeline_p(const FrameBuf& sb, const Frame
 }
 
 constexpr int kLabelGroupMax = 4;     // labels one wave may be given (it runs them in passes of as many as fit side by side)
+#ifndef DCMT_LABEL_WAVES
+#define DCMT_LABEL_WAVES 0
+#endif
 template <int K0KIND, bool NORM>
 __global__ __launch_bounds__(256)
+#if DCMT_LABEL_WAVES
+__attribute__((amdgpu_waves_per_eu(DCMT_LABEL_WAVES, DCMT_LABEL_WAVES)))
+#endif
 void k_label_stage_p(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels, int G,
                      const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
                      int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
@@ -454,7 +463,7 @@ void k_label_stage_p(const float* __restrict__ src, const int32_t* __restrict__ 
         const bool warm = ymin >= 10;
         const int nsteps = hmax + (warm ? H : 2 * H);
         // interior pass: warm, every column touched inside the image, every row fed or prefetched inside it
-        const bool interior = warm && xlo >= 0 && xhi < cols && ymax + nsteps + 7 + 4 < rows;   // (the step loop runs in eights, the loads 4 rows ahead)
+        const bool interior = warm && xlo >= 0 && xhi < cols && ymax + nsteps + 7 + DCMT_LABEL_PFD < rows;   // (the step loop runs in eights, the loads DCMT_LABEL_PFD rows ahead)
         if (interior) label_pipeline_p<K0KIND, NORM, true>(sb, lb, ob, L, y0, gx, ox0, ox1, true, nsteps, rows, cols, max_depth, thr, na, nb);
         else label_pipeline_p<K0KIND, NORM, false>(sb, lb, ob, L, y0, gx, ox0, ox1, warm, nsteps, rows, cols, max_depth, thr, na, nb);
     }
