@@ -61,7 +61,13 @@ struct dcmt_ctx {
     int pair = 1;                     // two columns per lane in H2..H6 (k_pre_p) where the width is even; env DCMT_PAIR=0 keeps k_pre_s
     int bands = 0;                    // row bands per strip in k_pre_p (0 = by batch size); env DCMT_BANDS
     int fp_pair = 0;                  // env DCMT_FP_PAIR=1: two columns per lane in H7..H11 (k_fp_p: 8 % fewer VALU instructions, but its ~200 VGPRs leave 2 waves per SIMD and it is slower)
-    int fp_q16 = 0;                   // env DCMT_FP_Q16=1: H7..H11 on 16-bit codes (k_fp_q) -- the caller vouches that every frame is a multiple of 1/256 m
+    int fp_q16 = 1;                   // X6 as 16-bit codes + k_fp_q wherever the frames allow it (multiples of 1/256 m: checked on the device, the f32
+                                      // kernels rerun behind a raised flag); env DCMT_FP_Q16=0 disables
+    unsigned short* x6q = nullptr;    // [max_batch][rows][cols] X6 as 16-bit codes (k_pre_p<Q16OUT> -> k_fp_q)
+    int* q16_bad = nullptr;           // raised by k_pre_p<Q16OUT> when a value it stored was not a code
+    int* q16_seen = nullptr;          // pinned host word (and its device address) the same kernel sets: the NEXT calls skip the 16-bit attempt
+    int* q16_seen_dev = nullptr;
+    int q16_skip = 0;                 // calls left without an attempt (after a raised flag: 63, then one more try)
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
@@ -228,6 +234,14 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     const hipStream_t ps = st;
     const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
     int rc = DCMT_OK, apps_all = 0;
+    // 16-bit X6: a frame that is no multiple of 1/256 m costs the attempt AND the f32 rerun; once a call has raised the flag (seen
+    // here at the start of a later call, without synchronising) the next 63 calls go straight to the f32 kernels.  Depths the uint16
+    // entry point converts itself are codes by construction and always take the 16-bit form.
+    bool q16_try = ctx->fp_q16 != 0;
+    if (q16_try && !d_src16) {
+        if (*(volatile int*)ctx->q16_seen) { *(volatile int*)ctx->q16_seen = 0; ctx->q16_skip = 63; }
+        if (ctx->q16_skip > 0) { --ctx->q16_skip; q16_try = false; }
+    }
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int nb = batch - f0 < chunk ? batch - f0 : chunk;
         const int xm = (ctx->xcd_map && nb % 8 == 0) ? 1 : 0;
@@ -240,6 +254,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         const float* cf = coef ? coef + 2 * (size_t)f0 : nullptr;
         // table mode: only the k_fp_s path reads X6 through the per-column table (the probes and the unfused kernels get a fully written X6)
         int bands = 1;                      // row bands of k_pre_p = table slots per frame
+        bool q16 = false;                   // this chunk's X6 is 16-bit codes (in ctx->x6q)
         int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tb : nullptr;   // chunks follow each other in the stream: each may use the whole table
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
@@ -265,25 +280,32 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 if (bands > rows / 32) bands = rows / 32 > 0 ? rows / 32 : 1;
                 if (bands > kMaxBands) bands = kMaxBands;
             }
-#define DCMT_PREP(KIND) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
+#define DCMT_PREP(KIND, QOUT, O6, QBAD, GATE) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
                 if (d_x4) { const int strips = (cols + G4::VW - 1) / G4::VW; \
-                    hipLaunchKernelGGL((k_pre_p<KIND, true, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt); } \
+                    hipLaunchKernelGGL((k_pre_p<KIND, true, false, false, QOUT>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, O6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } \
                 else { const int strips = (cols + G0::VW - 1) / G0::VW; \
-                    if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src16, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc, cnt); \
-                    else if (cf) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc, cnt); \
-                    else hipLaunchKernelGGL((k_pre_p<KIND, false, false>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, o6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt); } }
-            if (pair) {
-                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED) else DCMT_PREP(K0_DIAMOND)
+                    if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, true, false, QOUT>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src16, O6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); \
+                    else if (cf) { if constexpr (!QOUT) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, O6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } \
+                    else hipLaunchKernelGGL((k_pre_p<KIND, false, false, false, QOUT>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, O6, \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } }
+            // 16-bit X6 (k_pre_p<Q16OUT> -> k_fp_q): the whole chain in table mode, two columns per lane, the reference's constants, no
+            // normalisation in front (normalised depths are no multiples of 1/256)
+            q16 = q16_try && pair && tc && !cf && Q16::params_ok(p->max_depth, p->valid_thresh) && (uintptr_t)dst % 8 == 0 &&
+                  (!src16 || in_scale == 0.00390625f);
+            float* x6q = reinterpret_cast<float*>(ctx->x6q + f0 * fe);
+            if (q16) {
+                DCMT_HIP(ctx, hipMemsetAsync(ctx->q16_bad, 0, sizeof(int), ps));
+                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, true, x6q, ctx->q16_bad, (const int*)nullptr) else DCMT_PREP(K0_DIAMOND, true, x6q, ctx->q16_bad, (const int*)nullptr)
+            } else if (pair) {
+                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)nullptr) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)nullptr)
             } else {
                 if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
                 else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
             }
 #undef DCMT_PRE
-#undef DCMT_PREP
             DCMT_HIP(ctx, hipGetLastError());
             stamp(2);
             if (stop == DCMT_STAGE_EXTEND) continue;
@@ -298,12 +320,22 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const dim3 fpg = wave_grid(pstrips, nb, xm);
             // two columns per lane (k_fp_p) wherever a lane's 8-byte stores are aligned: even width, 8-byte aligned frames
             const bool fpp = ctx->fp_pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0);
-            const bool fpq = ctx->fp_q16 && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0) && Q16::params_ok(p->max_depth, p->valid_thresh);
-            if (fpq) {
+            const bool src16_q = d_src16 != nullptr;          // codes by construction: no rerun needed
+            if (q16) {
                 const int qstrips = (cols + FpP::VW - 1) / FpP::VW;
                 const dim3 qg = wave_grid(qstrips, nb, xm);
-                if (bl) hipLaunchKernelGGL((k_fp_q<true, false>), qg, b256, 0, st, (const void*)x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
-                else    hipLaunchKernelGGL((k_fp_q<false, false>), qg, b256, 0, st, (const void*)x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+                const void* xq = ctx->x6q + f0 * fe;
+                if (bl) hipLaunchKernelGGL((k_fp_q<true, true>), qg, b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+                else    hipLaunchKernelGGL((k_fp_q<false, true>), qg, b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+                if (!src16_q) {
+                    // frames that are no multiples of 1/256 m: both f32 kernels again, gated on the flag the attempt raised (they return at once otherwise)
+                    float* o6 = x6;
+                    const uint16_t* src16 = nullptr; const float* cf = nullptr; const hipStream_t ps = st;
+                    const float* src = (d_x4 ? d_x4 : d_src) + f0 * fe;
+                    if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)ctx->q16_bad) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)ctx->q16_bad)
+                    if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
+                    else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
+                }
             }
             else if (fpp) {
                 const int qstrips = (cols + FpP::VW - 1) / FpP::VW;
@@ -311,8 +343,9 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 if (bl) hipLaunchKernelGGL((k_fp_p<true>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
                 else    hipLaunchKernelGGL((k_fp_p<false>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
             }
-            else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
-            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+            else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
+            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
+#undef DCMT_PREP
             DCMT_HIP(ctx, hipGetLastError());
             stamp(3);
             ctx->last_has_loop = 1;
@@ -325,11 +358,12 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     for (int f = 0; f < batch; ++f) any |= ctx->h_counters[(size_t)f * kCntStride + 1] > 0;
                     if (!any) { if (p->verbose) for (int f = 0; f < batch; ++f) std::printf("0\n"); continue; }
                 }
-                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1, (const int*)tc, bands);
+                hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1, (const int*)tc, bands,
+                                   q16 ? (const unsigned short*)(ctx->x6q + f0 * fe) : (const unsigned short*)nullptr, (const int*)ctx->q16_bad);
                 int apps = 0;
                 const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
                     hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                                       fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr, 1);
+                                       fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr, 1, (const unsigned short*)nullptr, (const int*)nullptr);
                 }, &apps);
                 if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
                 if (lrc != DCMT_OK) rc = lrc;
@@ -343,7 +377,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             continue;
         }
         hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, x6, stop == DCMT_STAGE_FILL31 ? dst : pp0, cnt, rows, cols,
-                           fstrips, nb, xm, p->valid_thresh, 0, 0, (const int*)nullptr, 1);
+                           fstrips, nb, xm, p->valid_thresh, 0, 0, (const int*)nullptr, 1, (const unsigned short*)nullptr, (const int*)nullptr);
         DCMT_HIP(ctx, hipGetLastError());
         if (stop == DCMT_STAGE_FILL31) continue;
 
@@ -351,7 +385,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         int apps = 0;
         const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
             hipLaunchKernelGGL(k_fill_s, fgrid, dim3(256), 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
-                               fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr, 1);
+                               fstrips, nb, xm, p->valid_thresh, i, 0, (const int*)nullptr, 1, (const unsigned short*)nullptr, (const int*)nullptr);
         }, &apps);
         if (lrc != DCMT_OK && lrc != DCMT_E_NOT_CONVERGED) return lrc;
         if (lrc != DCMT_OK) rc = lrc;
@@ -697,6 +731,11 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + FTH_FEW - 1) / FTH_FEW) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->x6q, plane / 2 + 16) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->q16_bad, 256) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipHostMalloc((void**)&ctx->q16_seen, 64, hipHostMallocMapped) != hipSuccess) return fail(DCMT_E_NOMEM);
+    *ctx->q16_seen = 0;
+    if (hipHostGetDevicePointer((void**)&ctx->q16_seen_dev, ctx->q16_seen, 0) != hipSuccess) return fail(DCMT_E_HIP);
     // (first, last) table: one slot per frame and row band.  Bands are only chosen while frames x strips x bands stays near one
     // round of waves (run_chain_fused), so frames x bands <= max_batch + 2560; an explicit DCMT_BANDS may go up to kMaxBands each.
     const size_t tb_slots = ctx->bands > 0 ? (size_t)max_batch * kMaxBands : std::min<size_t>((size_t)max_batch * kMaxBands, (size_t)max_batch + 2560);
@@ -716,6 +755,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
     (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters); (void)hipFree(ctx->tb);
+    (void)hipFree(ctx->x6q); (void)hipFree(ctx->q16_bad); if (ctx->q16_seen) (void)hipHostFree(ctx->q16_seen);
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
     (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);

@@ -39,14 +39,6 @@ __device__ __forceinline__ unsigned qmin(unsigned a, unsigned b)
 }
 __device__ __forceinline__ unsigned umax2(unsigned a, unsigned b) { return a > b ? a : b; }
 
-struct Q16 {
-    static constexpr int OFFSET = 39935;                         // code = 256 x + OFFSET
-    static constexpr unsigned HOLE_MAX = 25 + OFFSET;            // x < 0.1f  <=>  256 x <= 25  <=>  code <= HOLE_MAX
-    static constexpr unsigned HOLE_MAX_HI = (HOLE_MAX << 16) | 0xffffu;   // the same test on the high half of a packed pair
-    __device__ static __forceinline__ unsigned code(float x) { return (unsigned)((int)__fmul_rn(x, 256.0f) + OFFSET); }
-    __device__ static __forceinline__ float value(unsigned c) { return __builtin_fmaf((float)c, 0.00390625f, -155.99609375f); }   // (c - 39935) / 256, exact
-    __host__ __device__ static bool params_ok(float max_depth, float thr) { return max_depth == 100.0f && thr == 0.1f; }
-};
 
 // shifts with 0 in the lane without a source (unsigned codes: 0 is the neutral element of max)
 __device__ __forceinline__ unsigned u_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); }

@@ -80,6 +80,16 @@ struct FrameBuf {
 };
 
 
+// 16-bit codes of depths that are multiples of 1/256 m (k_pre_p<Q16OUT> -> k_fp_q, dcmt_kernels_fp_q16.h has the argument)
+struct Q16 {
+    static constexpr int OFFSET = 39935;                         // code = 256 x + OFFSET: x = j / 256, j in [-39935, 25600]
+    static constexpr unsigned HOLE_MAX = 25 + OFFSET;            // x < 0.1f  <=>  256 x <= 25  <=>  code <= HOLE_MAX
+    static constexpr unsigned HOLE_MAX_HI = (HOLE_MAX << 16) | 0xffffu;   // the same test on the high half of a packed pair
+    __device__ static __forceinline__ unsigned code(float x) { return (unsigned)((int)__fmul_rn(x, 256.0f) + OFFSET); }
+    __device__ static __forceinline__ float value(unsigned c) { return __builtin_fmaf((float)c, 0.00390625f, -155.99609375f); }   // (c - 39935) / 256, exact
+    __host__ __device__ static bool params_ok(float max_depth, float thr) { return max_depth == 100.0f && thr == 0.1f; }
+};
+
 __device__ __forceinline__ int wave_max_i(int v)
 {
 #pragma unroll
@@ -856,7 +866,8 @@ __device__ __forceinline__ void row_scans3(float a, float b, float& pa, float& s
 
 __global__ __launch_bounds__(256)
 void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ counters,
-              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tb, int tbands)
+              int rows, int cols, int strips, int batch, int xcd_map, float thr, int app, int redo, const int* __restrict__ tb, int tbands,
+              const unsigned short* __restrict__ in16, const int* __restrict__ q16_bad)
 {
     const int lane = threadIdx.x & 63;
     int f, sg;
@@ -872,6 +883,10 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     const int gxc = min(max(gx, 0), cols - 1);
     const float* sp = in + fo + gxc;
     float* op = out + fo + gxc;
+    // in16: X6 was left as 16-bit codes (k_pre_p<Q16OUT>) unless that attempt raised *q16_bad and the f32 kernels reran into `in`
+    const bool q16 = in16 != nullptr && *q16_bad == 0;
+    const unsigned short* sq = in16 ? in16 + fo + gxc : nullptr;
+    auto ld_in = [&](size_t off) -> float { return q16 ? Q16::value(sq[off]) : sp[off]; };
     const int a_lo = ((lane - FillS::R) & 63) * 4, a_hi = ((lane + FillS::R) & 63) * 4;   // bpermute byte addresses
     // tb: `in` is an X6 whose extension zones were never written (k_pre_s / k_pre_p, table mode): the rows above a column's first
     // valid row equal that row, the rows below its last valid row equal that one, so the row index is clamped per lane
@@ -885,7 +900,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
     // step t handles the (row-clamped) input row v = t - 15 and emits output row o = t - 30
     constexpr int PFD = 8;
 #pragma unroll
-    for (int q = 0; q < PFD; ++q) PF[q] = sp[(size_t)min(max(min(max(q - FillS::R, 0), rows - 1), tl), bl) * cols];
+    for (int q = 0; q < PFD; ++q) PF[q] = ld_in((size_t)min(max(min(max(q - FillS::R, 0), rows - 1), tl), bl) * cols);
     float vprev = -FLT_MAX;
     int before = 0, after = 0;
     const int nsteps = rows + 2 * FillS::R;
@@ -894,7 +909,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
         for (int p = 0; p < 16; ++p) {
             const int t = t0 + p;
             const float x = PF[p];
-            PF[(p + PFD) & 15] = sp[(size_t)min(max(min(max(t + PFD - FillS::R, 0), rows - 1), tl), bl) * cols];
+            PF[(p + PFD) & 15] = ld_in((size_t)min(max(min(max(t + PFD - FillS::R, 0), rows - 1), tl), bl) * cols);
             XC[p] = x;
             // vertical: windows ending at row t of 2, 4, 8, 16, 31 rows
             const float w2 = fmax2(x, vprev);
@@ -962,8 +977,9 @@ template <bool BLUR>
 __global__ __launch_bounds__(256)
 void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
             int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb,
-            int tbands)
+            int tbands, const int* __restrict__ gate)
 {
+    if (gate && *gate == 0) return;          // the f32 rerun behind a 16-bit attempt (k_fp_q): only if that attempt raised its flag
     // per wave, three 15-step delay lines: centre values, A's 16-row maxima (64 lanes each), B's 16-row
     // maxima (only its 30 halo lanes: packed to 32) -- 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
     __shared__ float s_delay[4][16 * (64 + 64 + 32)];

@@ -75,14 +75,23 @@ constexpr int kMaxBands = 8;                 // row bands per strip (table slots
 // with cold rings (exactly like the start below the leading empty rows) and accounts for the x5 rows [r0, r1) only; the
 // per-column (ti, bi) of the bands go to one table slot per band, which the reader combines (table_rows), which is why
 // bands need table mode.
-template <int K0KIND, bool START4 = false, bool U16 = false, bool NORM = false>
+// Q16OUT: X6 leaves as 16-bit codes (Q16 below: code = 256 x + 39935, two columns per dword) for k_fp_q -- half the X6 traffic.
+// Exact only if every value stored is a multiple of 1/256 in the code range, which holds whenever the frame's depths are
+// (the KITTI format); the kernel checks it on every value it really stores and raises *q16_bad otherwise (the caller then
+// reruns the f32 kernels, gated on that flag).  Table mode only.
+// gate: a launch that only runs if *gate != 0 (the f32 rerun behind a Q16 attempt); nullptr = always.
+// q16_seen: a word of mapped host memory set together with the flag, so that the host can stop attempting on data that is no grid.
+
+template <int K0KIND, bool START4 = false, bool U16 = false, bool NORM = false, bool Q16OUT = false>
 __global__ __launch_bounds__(256)
 void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips, int bands,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
-             int* __restrict__ tb, int* __restrict__ counters)
+             int* __restrict__ tb, int* __restrict__ counters, int* __restrict__ q16_bad, const int* __restrict__ gate, int* __restrict__ q16_seen)
 {
     static_assert(!(U16 && START4), "the uint16 ingest is the first kernel of the path");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
+    static_assert(!(NORM && Q16OUT), "normalised frames are not multiples of 1/256");
+    if (gate && *gate == 0) return;
     const float* src = static_cast<const float*>(src_);
     using G = PreP<K0KIND, START4>;
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
@@ -101,10 +110,13 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     float na = 1.0f, nb = 0.0f;
     if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
     FrameBuf ob, ib;
-    ob.init(x6 + fo, (size_t)rows * cols);
+    if constexpr (Q16OUT) ob.init(reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x6) + fo), (size_t)rows * cols / 2);
+    else ob.init(x6 + fo, (size_t)rows * cols);
     if constexpr (U16) ib.init(reinterpret_cast<const float*>(static_cast<const uint16_t*>(src_) + fo), (size_t)rows * cols / 2);
     else ib.init(src + fo, (size_t)rows * cols);
-    const unsigned oc = 4u * (unsigned)gxc;
+    const unsigned oc = 4u * (unsigned)gxc;                          // byte offset of the column pair in an f32 row
+    const unsigned qc = 2u * (unsigned)gxc;                          // ... in a row of 16-bit codes
+    unsigned bad = 0;                                                // Q16OUT: a stored value was not a code
     auto load_row = [&](int r) -> F2 {            // image row r (already clamped) of this lane's two columns, in metres
         if constexpr (U16) {
             const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(ib.rs, 2u * (unsigned)gxc, r * cols * 2, 0);
@@ -236,7 +248,18 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // step by every lane, aimed past the buffer when there is nothing to write (no branch in the row step)
             // (a band below the first one stores all its rows: the rows between a column's first valid row in an upper band and its
             // first one here are real holes that the reader looks at)
-            st2(ob, (inrows && outlane && (band > 0 || m >= min(tie, tio))) ? oc : kDropOffset, inrows ? m : 0, cols, x5);
+            const bool real = inrows && outlane && (band > 0 || m >= min(tie, tio));
+            if constexpr (Q16OUT) {
+                const float te = __fmul_rn(x5.e, 256.0f), to = __fmul_rn(x5.o, 256.0f);
+                const int ce = (int)te, co = (int)to;
+                const unsigned ue = (unsigned)(ce + Q16::OFFSET), uo = (unsigned)(co + Q16::OFFSET);
+                const unsigned diff = (__builtin_bit_cast(unsigned, (float)ce) ^ __builtin_bit_cast(unsigned, te)) |
+                                      (__builtin_bit_cast(unsigned, (float)co) ^ __builtin_bit_cast(unsigned, to)) | ((ue | uo) >> 16);
+                bad |= real ? diff : 0u;
+                __builtin_amdgcn_raw_buffer_store_b32(ue | (uo << 16), ob.rs, real ? qc : kDropOffset, (inrows ? m : 0) * cols * 2, 0);
+            } else {
+                st2(ob, real ? oc : kDropOffset, inrows ? m : 0, cols, x5);
+            }
         }
     }
     if (tb) {
@@ -249,15 +272,24 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             const bool ee = bie < 0, eo = bio < 0;
             if ((ee | eo) && band == bands - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (ee) ob.st_at(oc + 4u * (unsigned)((rows - 1) * cols), 100.0f);
-                if (eo) ob.st_at(oc + 4u + 4u * (unsigned)((rows - 1) * cols), 100.0f);
+                if constexpr (Q16OUT) {                                   // 100 = code 65535
+                    if (ee) __builtin_amdgcn_raw_buffer_store_b16((short)0xffff, ob.rs, qc + 2u * (unsigned)((rows - 1) * cols), 0, 0);
+                    if (eo) __builtin_amdgcn_raw_buffer_store_b16((short)0xffff, ob.rs, qc + 2u + 2u * (unsigned)((rows - 1) * cols), 0, 0);
+                } else {
+                    if (ee) ob.st_at(oc + 4u * (unsigned)((rows - 1) * cols), 100.0f);
+                    if (eo) ob.st_at(oc + 4u + 4u * (unsigned)((rows - 1) * cols), 100.0f);
+                }
             }
             const bool tr = bands == 1;                                  // unbanded: the translation of an empty column is done here
             *reinterpret_cast<int2*>(tt + gx) = make_int2(ee && tr ? rows - 1 : tie, eo && tr ? rows - 1 : tio);
             *reinterpret_cast<int2*>(bt + gx) = make_int2(ee && tr ? rows - 1 : bie, eo && tr ? rows - 1 : bio);
         }
+        if constexpr (Q16OUT) {
+            if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull && lane == 0) { atomicOr(q16_bad, 1); *q16_seen = 1; }   // q16_seen: host memory the next call looks at
+        }
         return;
     }
+    if constexpr (Q16OUT) return;                                // (codes need the table: the host never launches this)
     // ---- H6 as the reference writes it (LO :122-127): rows >= last valid take its value, rows <= first valid take its
     // value; a column without valid pixels ends as 100 everywhere (:110, :125-127).  One column at a time (4-byte stores).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's own stores, before it reads some of them back

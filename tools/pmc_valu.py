@@ -16,7 +16,7 @@ with open(sys.argv[1]) as f:
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"kernels": {}, "units": "mean per dispatch; SQ_ACTIVE_INST_VALU in quad-cycles summed over all SIMDs"}
 for k, cs in sorted(acc.items()):
-    if not ("k_pre_s" in k or "k_pre_p" in k or "k_fp_s" in k):
+    if not ("k_pre_s" in k or "k_pre_p" in k or "k_fp_s" in k or "k_fp_q" in k or "k_fp_p" in k):
         continue        # the redo launches return at once
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     out["kernels"][k] = {"insts_valu": m.get("SQ_INSTS_VALU"), "active_inst_valu": m.get("SQ_ACTIVE_INST_VALU"),
