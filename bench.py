@@ -169,6 +169,19 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
     out["4_per_gpu_share"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {b128} frames per step (the per-GPU shard of 1024 frames on 8 GPUs)",
                               "value": b128 * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(b128 * BYTES_PER_FRAME, ms)}
     c4.close()
+    # the same step on frames that are NOT multiples of 1/256 m (every depth scaled by 1.001): the 16-bit form of X6 does not apply, the
+    # first call pays the attempt and the f32 rerun, the following ones go straight to the f32 kernels (k_pre_p -> k_fp_s) -- the
+    # rate a caller with arbitrary f32 depths gets
+    cg = Context(local_rank, ROWS, COLS, B)
+    d_off = d_src * 1.001
+    for _ in range(2):
+        cg.complete_dev(d_off, d_dst, params, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+    ms = timed(torch, lambda: cg.complete_dev(d_off, d_dst, params, stream=stream.cuda_stream), steps, stream)
+    out["4_off_grid_f32"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {B} frames per step whose depths are no multiples of 1/256 m: f32 kernels throughout (X6 as f32)",
+                             "value": B * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(B * BYTES_PER_FRAME, ms)}
+    cg.close()
+    del d_off
     # the same 1024-frame step as four parts of 256 frames in flight on four streams, after the GPU has been busy for a while
     if B >= 1024:
         n4 = B // 4
@@ -488,14 +501,15 @@ def main():
         ctx.set_kernel_timing(False)
         ctx.close()
         roof = hbm_roofline(B * BYTES_PER_FRAME, gpu_ms_per_step)
-        roof["kernel"] = ("whole cascade per step = k_pre_p + k_fp_s (+ 3 redo launches that return at once) of every part, HIP events on the launch streams "
+        roof["kernel"] = ("whole cascade per step = k_pre_p + k_fp_q (the frames are multiples of 1/256 m, the KITTI depth format: X6 crosses HBM as 16-bit codes; "
+                          "+ the gated f32 rerun and 3 redo launches, which return at once) of every part, HIP events on the launch streams "
                           "around the K timed steps (first start to last end); with more than one part the kernels of different parts overlap, so the per-kernel "
                           "durations of a profile add up to more than the step; per_kernel and single_context: the same frames through ONE context on one stream "
                           "(the library's own events, dcmt_set_kernel_timing, 5 extra steps); rocprofv3 averages of that single-context step in profiles/")
         roof["single_context"] = dict(hbm_roofline(B * BYTES_PER_FRAME, one_ms), value=B * 1e3 / one_ms, unit="frames/s",
                                       note="one dcmt_complete_f32_dev call per step on one stream: the kernels run one after the other")
         roof["per_kernel"] = {"k_pre": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
-                              "k_fp_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="reads X6, writes the dense frame"),
+                              "k_fp_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="the H7..H11 kernel (k_fp_q on grid frames, k_fp_s otherwise) and the gated rerun launches behind it: reads X6, writes the dense frame"),
                               "redo_launches_ms": kt[3]}
         tr = load_profile_json("traffic_latest.json")
         roof["traffic"] = tr.get("hbm_bytes_per_step") if tr else None
@@ -519,7 +533,7 @@ def main():
             "metric": METRIC, "value": total * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic KITTI-like sparse depth (depth_completion_mt_amd/synth.py), {uniq} distinct frames per GPU tiled to {B}",
+            "data": f"synthetic KITTI-like sparse depth (depth_completion_mt_amd/synth.py: depths are multiples of 1/256 m like a KITTI uint16 PNG / 256), {uniq} distinct frames per GPU tiled to {B}",
             "config": {"workload": (f"DC_lidar_only img_completion, {COLS}x{ROWS} f32, {total} device-resident frames per step "
                                     + (f"= {args.batch} per GPU (weak scaling)" if args.weak else
                                        f"sharded per frame over {world} GPU(s) = {B} per GPU (BASELINE configs[4]; strong scaling)")),

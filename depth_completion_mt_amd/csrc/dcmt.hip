@@ -63,6 +63,9 @@ struct dcmt_ctx {
     int fp_pair = 0;                  // env DCMT_FP_PAIR=1: two columns per lane in H7..H11 (k_fp_p: 8 % fewer VALU instructions, but its ~200 VGPRs leave 2 waves per SIMD and it is slower)
     int fp_q16 = 1;                   // X6 as 16-bit codes + k_fp_q wherever the frames allow it (multiples of 1/256 m: checked on the device, the f32
                                       // kernels rerun behind a raised flag); env DCMT_FP_Q16=0 disables
+    int q16_min_waves = 10240;        // ... and the batch is large enough: k_fp_q has half as many, longer waves than k_fp_s (3 per SIMD instead of 4), so it
+                                      // only pays from ~3.5 rounds of them on (measured, 352x1216: 768 frames -2 %, 1024 frames +3 %; 128 frames -15 %);
+                                      // env DCMT_Q16_MIN_WAVES
     unsigned short* x6q = nullptr;    // [max_batch][rows][cols] X6 as 16-bit codes (k_pre_p<Q16OUT> -> k_fp_q)
     int* q16_bad = nullptr;           // raised by k_pre_p<Q16OUT> when a value it stored was not a code
     int* q16_seen = nullptr;          // pinned host word (and its device address) the same kernel sets: the NEXT calls skip the 16-bit attempt
@@ -293,7 +296,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                                        rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } }
             // 16-bit X6 (k_pre_p<Q16OUT> -> k_fp_q): the whole chain in table mode, two columns per lane, the reference's constants, no
             // normalisation in front (normalised depths are no multiples of 1/256)
-            q16 = q16_try && pair && tc && !cf && Q16::params_ok(p->max_depth, p->valid_thresh) && (uintptr_t)dst % 8 == 0 &&
+            q16 = q16_try && (long long)nb * ((cols + FpP::VW - 1) / FpP::VW) >= ctx->q16_min_waves && pair && tc && !cf && Q16::params_ok(p->max_depth, p->valid_thresh) && (uintptr_t)dst % 8 == 0 &&
                   (!src16 || in_scale == 0.00390625f);
             float* x6q = reinterpret_cast<float*>(ctx->x6q + f0 * fe);
             if (q16) {
@@ -716,6 +719,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_FUSE_FP"); if (e) ctx->fuse_fp = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FP_PAIR"); if (e) ctx->fp_pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FP_Q16"); if (e) ctx->fp_q16 = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_Q16_MIN_WAVES"); if (e) ctx->q16_min_waves = std::atoi(e); }
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }

@@ -129,8 +129,17 @@ struct MedianColumnQ {       // MedianColumn (dcmt_median.h) on packed pairs
     }
 };
 
+#ifndef DCMT_FPQ_WAVES
+#define DCMT_FPQ_WAVES 0
+#endif
+#ifndef DCMT_FPQ_PFD
+#define DCMT_FPQ_PFD 6
+#endif
 template <bool BLUR, bool X6U16>
 __global__ __launch_bounds__(256)
+#if DCMT_FPQ_WAVES
+__attribute__((amdgpu_waves_per_eu(DCMT_FPQ_WAVES, DCMT_FPQ_WAVES)))
+#endif
 void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restrict__ counters,
             int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb,
             int tbands)
@@ -206,7 +215,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     for (int q = 0; q < 8; ++q) DL[q] = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; dl_b[q][lb] = xb0; }
-    constexpr int PFD = 6;
+    constexpr int PFD = DCMT_FPQ_PFD;        // rows of load lookahead
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
         const Raw r = ld_row(min(max(q + (warm ? 16 : 0) - 15, 0), rows - 1));

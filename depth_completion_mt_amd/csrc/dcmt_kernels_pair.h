@@ -82,8 +82,14 @@ constexpr int kMaxBands = 8;                 // row bands per strip (table slots
 // gate: a launch that only runs if *gate != 0 (the f32 rerun behind a Q16 attempt); nullptr = always.
 // q16_seen: a word of mapped host memory set together with the flag, so that the host can stop attempting on data that is no grid.
 
+#ifndef DCMT_PRE_WAVES
+#define DCMT_PRE_WAVES 0
+#endif
 template <int K0KIND, bool START4 = false, bool U16 = false, bool NORM = false, bool Q16OUT = false>
 __global__ __launch_bounds__(256)
+#if DCMT_PRE_WAVES
+__attribute__((amdgpu_waves_per_eu(DCMT_PRE_WAVES, DCMT_PRE_WAVES)))
+#endif
 void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips, int bands,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
              int* __restrict__ tb, int* __restrict__ counters, int* __restrict__ q16_bad, const int* __restrict__ gate, int* __restrict__ q16_seen)
