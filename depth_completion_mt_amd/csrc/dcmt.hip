@@ -63,6 +63,9 @@ struct dcmt_ctx {
     int fp_pair = 0;                  // env DCMT_FP_PAIR=1: two columns per lane in H7..H11 (k_fp_p: 8 % fewer VALU instructions, but its ~200 VGPRs leave 2 waves per SIMD and it is slower)
     int fp_q16 = 1;                   // X6 as 16-bit codes + k_fp_q wherever the frames allow it (multiples of 1/256 m: checked on the device, the f32
                                       // kernels rerun behind a raised flag); env DCMT_FP_Q16=0 disables
+    int q16_breg = 1;                 // k_fp_q with the halo columns in a second register (120 output columns per wave, 3 waves per SIMD); 0 = wider strip
+                                      // overlap instead (88 output columns, 4 waves per SIMD: measured 2.5 % slower -- the kernel is bound by issue, not by
+                                      // occupancy); env DCMT_Q16_BREG
     int q16_min_waves = 10240;        // ... and the batch is large enough: k_fp_q has half as many, longer waves than k_fp_s (3 per SIMD instead of 4), so it
                                       // only pays from ~3.5 rounds of them on (measured, 352x1216: 768 frames -2 %, 1024 frames +3 %; 128 frames -15 %);
                                       // env DCMT_Q16_MIN_WAVES
@@ -325,11 +328,13 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const bool fpp = ctx->fp_pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0);
             const bool src16_q = d_src16 != nullptr;          // codes by construction: no rerun needed
             if (q16) {
-                const int qstrips = (cols + FpP::VW - 1) / FpP::VW;
-                const dim3 qg = wave_grid(qstrips, nb, xm);
                 const void* xq = ctx->x6q + f0 * fe;
-                if (bl) hipLaunchKernelGGL((k_fp_q<true, true>), qg, b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
-                else    hipLaunchKernelGGL((k_fp_q<false, true>), qg, b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
+#define DCMT_FPQ(BL, BREG) { const int qstrips = (cols + FpQ::vw<BREG>() - 1) / FpQ::vw<BREG>(); \
+                    hipLaunchKernelGGL((k_fp_q<BL, true, BREG>), wave_grid(qstrips, nb, xm), b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, \
+                                       p->max_depth, p->valid_thresh, (const int*)tc, bands); }
+                if (ctx->q16_breg) { if (bl) DCMT_FPQ(true, true) else DCMT_FPQ(false, true) }
+                else               { if (bl) DCMT_FPQ(true, false) else DCMT_FPQ(false, false) }
+#undef DCMT_FPQ
                 if (!src16_q) {
                     // frames that are no multiples of 1/256 m: both f32 kernels again, gated on the flag the attempt raised (they return at once otherwise)
                     float* o6 = x6;
@@ -720,6 +725,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_FP_PAIR"); if (e) ctx->fp_pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_FP_Q16"); if (e) ctx->fp_q16 = std::atoi(e); }
     { const char* e = std::getenv("DCMT_Q16_MIN_WAVES"); if (e) ctx->q16_min_waves = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_Q16_BREG"); if (e) ctx->q16_breg = std::atoi(e); }
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void sort5_pair(F2 x, float (&se)[5], float (&so)[5])
 
 // PostPipe (dcmt_kernels_fused.h) for two columns per lane, MODE 11 only.  Step u takes X7 row clamp(u - 2), finishes the
 // median of image row u - 4 and the output of image row u - 6.
-template <bool BLUR>
+template <bool BLUR, int HALO = FpP::H>
 struct PostPipeP {
     MedianColumn mce, mco;
     F2 G1[8], MR[8];
@@ -102,7 +102,7 @@ struct PostPipeP {
         gx = gx0 + 2 * lane;
         ob = 4u * (unsigned)min(max(gx, 0), cols - 2);
         outside = gx < 0 || gx >= cols;                            // cols and gx are even: both columns inside or both outside
-        outlane = !outside && 2 * lane >= FpP::H && 2 * lane < 128 - FpP::H;
+        outlane = !outside && 2 * lane >= HALO && 2 * lane < 128 - HALO;
         // reflect-101 sources of the Gaussian's out-of-image columns: parity is preserved (cols is even), so E comes from an E slot, O from an O slot
         rle = (reflect101(gx, cols) - gx0) >> 1;
         rlo = (reflect101(gx + 1, cols) - 1 - gx0) >> 1;

@@ -57,6 +57,15 @@ __device__ __forceinline__ void u_row_scans4(unsigned a, unsigned b, unsigned& p
 #undef DCMT_U4
 }
 
+__device__ __forceinline__ void u_row_scans2(unsigned a, unsigned& pa, unsigned& sa)
+{
+    pa = a; sa = a;
+#define DCMT_U2(N) "v_max_u32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                   "v_max_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" DCMT_U2(1) "s_nop 0\n\t" DCMT_U2(2) "s_nop 0\n\t" DCMT_U2(4) "s_nop 0\n\t" DCMT_U2(8) : "+v"(pa), "+v"(sa));
+#undef DCMT_U2
+}
+
 // The exact 5x5 median of dcmt_median.h on packed pairs: the two-input networks of median_shared_nets.h (the three-input
 // forms need v_min3 / v_max3 / v_med3, which have no packed 16-bit version).
 #define DCMT_QCX(a, b)   { const unsigned lo_ = qmin(v[a], v[b]); v[b] = qmax(v[a], v[b]); v[a] = lo_; }
@@ -135,7 +144,15 @@ struct MedianColumnQ {       // MedianColumn (dcmt_median.h) on packed pairs
 #ifndef DCMT_FPQ_PFD
 #define DCMT_FPQ_PFD 6
 #endif
-template <bool BLUR, bool X6U16>
+// BREG = true: the 30 halo columns of the 31-wide maximum ride in a second register (k_fp_p's layout): 120 output columns per wave,
+//   144 VGPRs, 3 waves per SIMD.  BREG = false: no second register -- the strips overlap by the halo instead (X7 is exact for the
+//   lanes 8..55 = 96 columns, 88 of them output): a fifth less work per wave, a quarter more waves, and few enough VGPRs for 4
+//   waves per SIMD.
+struct FpQ {
+    template <bool BREG> static constexpr int halo() { return BREG ? FpP::H : 16 + FpP::H; }
+    template <bool BREG> static constexpr int vw() { return 128 - 2 * halo<BREG>(); }
+};
+template <bool BLUR, bool X6U16, bool BREG = true>
 __global__ __launch_bounds__(256)
 #if DCMT_FPQ_WAVES
 __attribute__((amdgpu_waves_per_eu(DCMT_FPQ_WAVES, DCMT_FPQ_WAVES)))
@@ -145,14 +162,15 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
             int tbands)
 {
     // per wave: centre values and A's 18-row maxima (packed pairs, one word per lane), B's 18-row maxima
-    __shared__ unsigned s_delay[4][16 * (64 + 64 + 32)];            // 10 KiB per wave, 40 KiB per workgroup: 4 fit a CU
+    __shared__ unsigned s_delay[4][16 * (64 + 64 + (BREG ? 32 : 0))];   // 10 (8) KiB per wave, 40 (32) KiB per workgroup
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int f, strip;
     if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;
     int* cnt = frame_counters(counters, f);
     const size_t fo = (size_t)f * rows_all * cols;
-    const int gx0 = strip * FpP::VW - FpP::H;
+    constexpr int HALO = FpQ::halo<BREG>(), VW = FpQ::vw<BREG>();
+    const int gx0 = strip * VW - HALO;
     const int gxe = gx0 + 2 * lane;
     // B, one column per lane, unpacked (k_fp_p's layout).  The dead lanes 16..47 (two whole DPP rows) shadow lane 0: same column,
     // same values, same delay-line word -- their stores write what lane 0 writes
@@ -163,7 +181,8 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     if (tb) {
         table_rows(tb, f, cols, tbands, rows_all, gxec, tie, bie);
         table_rows(tb, f, cols, tbands, rows_all, gxoc, tio, bio);
-        table_rows(tb, f, cols, tbands, rows_all, gxbc, tib, bib);
+        if constexpr (BREG) table_rows(tb, f, cols, tbands, rows_all, gxbc, tib, bib);
+        else tib = 0x7fffffff;
         V = __builtin_amdgcn_readfirstlane(max(wave_min_i(min(min(tie, tio), tib)) - 8, 0));
     }
     const int rows = rows_all - V;
@@ -183,12 +202,13 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     };
     struct Raw { unsigned e, o, b; };
     auto ld_row = [&](int row) -> Raw {                              // row relative to V, already clamped to [0, rows)
-        return {ld_code(clamp3(sbe + (unsigned)row * rowb, fle, cee)), ld_code(clamp3(sbo + (unsigned)row * rowb, flo, ceo)),
-                ld_code(clamp3(sbb + (unsigned)row * rowb, flb, ceb))};
+        Raw r = {ld_code(clamp3(sbe + (unsigned)row * rowb, fle, cee)), ld_code(clamp3(sbo + (unsigned)row * rowb, flo, ceo)), 0u};
+        if constexpr (BREG) r.b = ld_code(clamp3(sbb + (unsigned)row * rowb, flb, ceb));
+        return r;
     };
     auto pack = [](unsigned e, unsigned o) -> unsigned { return e | (o << 16); };
     const bool outside = gxe < 0 || gxe >= cols;
-    const bool own = !outside && 2 * lane >= FpP::H && 2 * lane < 128 - FpP::H;
+    const bool own = !outside && 2 * lane >= HALO && 2 * lane < 128 - HALO;
     const unsigned long long own_mask = __ballot(own);
     const bool edge_strip = gx0 < 0 || gx0 + 127 >= cols;
     const int rep_l = min(max((0 - gx0) >> 1, 0), 63), rep_r = min(max((cols - 2 - gx0) >> 1, 0), 63);
@@ -200,7 +220,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     unsigned (*dl_b)[32] = reinterpret_cast<unsigned (*)[32]>(sd + 16 * 128);
     const int lb = lane < 16 ? lane : (lane >= 48 ? lane - 32 : 0);
 
-    PostPipeP<BLUR> pipe;                                            // only its after_median() half is used
+    PostPipeP<BLUR, HALO> pipe;                                      // only its after_median() half is used
     pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
     MedianColumnQ mc;
     mc.init();
@@ -214,7 +234,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
 #pragma unroll
     for (int q = 0; q < 8; ++q) DL[q] = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; dl_b[q][lb] = xb0; }
+    for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; if constexpr (BREG) dl_b[q][lb] = xb0; }
     constexpr int PFD = DCMT_FPQ_PFD;        // rows of load lookahead
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
@@ -256,32 +276,50 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
         if (o >= rows) { asm volatile("" ::); x7 = x7_prev; }
         x7_prev = x7;
         // vertical 31-max: A packed (two-input instructions), B unpacked
-        const unsigned w2a = qmax(xa, vpa), w2b = umax2(xb, vpb);
-        vpa = xa; vpb = xb;
-        W2A[p] = w2a; W2B[p] = w2b;
+        const unsigned w2a = qmax(xa, vpa);
+        vpa = xa;
+        W2A[p] = w2a;
         const unsigned w6a = qmax(qmax(w2a, W2A[(p + 14) & 15]), W2A[(p + 12) & 15]);
-        const unsigned w6b = umax2(umax2(w2b, W2B[(p + 14) & 15]), W2B[(p + 12) & 15]);
-        W6A[p] = w6a; W6B[p] = w6b;
+        W6A[p] = w6a;
         const unsigned w18a = qmax(qmax(w6a, W6A[(p + 10) & 15]), W6A[(p + 4) & 15]);
-        const unsigned w18b = umax2(umax2(w6b, W6B[(p + 10) & 15]), W6B[(p + 4) & 15]);
-        const unsigned v = nxt_c, w18a_old = nxt_a, w18b_old = nxt_b;
+        const unsigned v = nxt_c, w18a_old = nxt_a;
         nxt_c = dl_c[(p + 2) & 15][lane];
         nxt_a = dl_a[(p + 4) & 15][lane];
-        nxt_b = dl_b[(p + 4) & 15][lb];
         dl_c[p][lane] = xa;
         dl_a[p][lane] = w18a;
-        dl_b[p][lb] = w18b;
-        const unsigned w31a = qmax(w18a, w18a_old), w31b = umax2(w18b, w18b_old);
+        const unsigned w31a = qmax(w18a, w18a_old);
+        unsigned w31b = 0;
+        if constexpr (BREG) {
+            const unsigned w2b = umax2(xb, vpb);
+            vpb = xb;
+            W2B[p] = w2b;
+            const unsigned w6b = umax2(umax2(w2b, W2B[(p + 14) & 15]), W2B[(p + 12) & 15]);
+            W6B[p] = w6b;
+            const unsigned w18b = umax2(umax2(w6b, W6B[(p + 10) & 15]), W6B[(p + 4) & 15]);
+            const unsigned w18b_old = nxt_b;
+            nxt_b = dl_b[(p + 4) & 15][lb];
+            dl_b[p][lb] = w18b;
+            w31b = umax2(w18b, w18b_old);
+        }
         const unsigned long long vme = __builtin_amdgcn_ballot_w64((v << 16) <= Q16::HOLE_MAX_HI), vmo = __builtin_amdgcn_ballot_w64(v <= Q16::HOLE_MAX_HI);
         if ((vme | vmo) != 0ull) {
             // horizontal 31-max: k_fp_p's scheme on the unpacked halves
             const unsigned e = w31a & 0xffffu, od = w31a >> 16;
-            const unsigned bo = u_row_ror8(w31b);
-            unsigned pa, sa, pb, sb;
-            u_row_scans4(umax2(e, od), umax2(w31b, bo), pa, sa, pb, sb);
-            const unsigned pxa = u_row_shr1(pa), sxa = u_row_shl1(sa), pxb = u_row_shr1(pb), sxb = u_row_shl1(sb);
-            const unsigned sx = b_hi ? sxb : sxa, so = umax2(b_hi ? bo : od, sx);
-            const unsigned px = b_lo ? pxb : pxa, pe = umax2(b_lo ? w31b : e, px);
+            unsigned sx, so, px, pe;
+            if constexpr (BREG) {
+                const unsigned bo = u_row_ror8(w31b);
+                unsigned pa, sa, pb, sb;
+                u_row_scans4(umax2(e, od), umax2(w31b, bo), pa, sa, pb, sb);
+                const unsigned pxa = u_row_shr1(pa), sxa = u_row_shl1(sa), pxb = u_row_shr1(pb), sxb = u_row_shl1(sb);
+                sx = b_hi ? sxb : sxa; so = umax2(b_hi ? bo : od, sx);
+                px = b_lo ? pxb : pxa; pe = umax2(b_lo ? w31b : e, px);
+            } else {
+                // (the fetches of lanes 0..7 and 56..63 wrap around the wave: their X7 is not exact, and nothing reads it)
+                unsigned pa, sa;
+                u_row_scans2(umax2(e, od), pa, sa);
+                px = u_row_shr1(pa); sx = u_row_shl1(sa);
+                so = umax2(od, sx); pe = umax2(e, px);
+            }
             pend_f1 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)so);
             pend_f2 = (unsigned)__builtin_amdgcn_ds_bpermute(a_p8, (int)px);
             pend_f3 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)sx);

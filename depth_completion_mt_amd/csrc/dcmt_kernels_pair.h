@@ -256,11 +256,15 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // first one here are real holes that the reader looks at)
             const bool real = inrows && outlane && (band > 0 || m >= min(tie, tio));
             if constexpr (Q16OUT) {
-                const float te = __fmul_rn(x5.e, 256.0f), to = __fmul_rn(x5.o, 256.0f);
-                const int ce = (int)te, co = (int)to;
-                const unsigned ue = (unsigned)(ce + Q16::OFFSET), uo = (unsigned)(co + Q16::OFFSET);
-                const unsigned diff = (__builtin_bit_cast(unsigned, (float)ce) ^ __builtin_bit_cast(unsigned, te)) |
-                                      (__builtin_bit_cast(unsigned, (float)co) ^ __builtin_bit_cast(unsigned, to)) | ((ue | uo) >> 16);
+                // code = 256 x + 39935 through the float adder: y = fma(x, 256, 39935 + 2^23) lies in [2^23, 2^24) for every code, where the
+                // low mantissa bits ARE the integer -- no v_cvt (adds and logic ops issue beside the chain's max / min instructions).
+                // Exact iff 256 x is an integer in range: then y - (39935 + 2^23) gives 256 x back bit for bit; anything else (a fraction,
+                // -0.0, a value out of range, NaN, Inf) leaves a difference or a code above 16 bits.
+                constexpr float kMagic = 8428543.0f;                     // 39935 + 8388608
+                const float ye = __builtin_fmaf(x5.e, 256.0f, kMagic), yo = __builtin_fmaf(x5.o, 256.0f, kMagic);
+                const unsigned ue = __builtin_bit_cast(unsigned, ye) - 0x4B000000u, uo = __builtin_bit_cast(unsigned, yo) - 0x4B000000u;
+                const unsigned diff = (__builtin_bit_cast(unsigned, __fsub_rn(ye, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.e, 256.0f))) |
+                                      (__builtin_bit_cast(unsigned, __fsub_rn(yo, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.o, 256.0f))) | ((ue | uo) >> 16);
                 bad |= real ? diff : 0u;
                 __builtin_amdgcn_raw_buffer_store_b32(ue | (uo << 16), ob.rs, real ? qc : kDropOffset, (inrows ? m : 0) * cols * 2, 0);
             } else {
