@@ -30,6 +30,11 @@
  * input frame gives an unspecified (but memory-safe) result in the pixels its windows reach.
  * The reference's own result for such pixels depends on the min/max flavour of the OpenCV
  * build (SIMD vs scalar), so there is nothing to be bit-exact with.  -0.0 is treated as 0.0.
+ *
+ * Depth grids: frames whose depths are all multiples of 1/256 m below 256 m -- what a KITTI depth PNG / 256 holds,
+ * DC_lidar_only/main.cpp:75-82 -- let large device batches keep their intermediate image as 16-bit integers.  The library
+ * finds that out itself on the device (and repeats the step with its f32 kernels when a frame turns out otherwise); results
+ * are the same bits either way, and no promise about the values is asked of the caller.
  */
 #ifndef DCMT_H
 #define DCMT_H
@@ -123,7 +128,7 @@ int dcmt_device_count(void);
 
 /* Creates a context on `device` able to process up to max_batch frames of up to
  * max_rows x max_cols per call.  Allocates all device scratch up front (about
- * 12 B per pixel per frame of max_batch) so the call path never allocates.  A frame may hold at most 2^29 - 1
+ * 14 B per pixel per frame of max_batch) so the call path never allocates.  A frame may hold at most 2^29 - 1
  * pixels (it is addressed with 32-bit byte offsets); max_batch at most 65535. */
 int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx **out);
 void dcmt_destroy(dcmt_ctx *ctx);
