@@ -77,6 +77,62 @@ def test_fuzz_against_oracle(seed):
             assert_bit_equal(got[f], ref, what + f" frame {f}")
 
 
+def _grid_frame(g, rows, cols):
+    """depths that are multiples of 1/256 m (a uint16 payload / 256), with the values where the 16-bit codes have their edges"""
+    density = (0.0, 0.01, 0.05, 0.3, 1.0)[g.integers(0, 5)]
+    k = np.where(g.random((rows, cols)) < density, g.integers(52, 22000, (rows, cols)), 0)
+    kind = g.integers(0, 4)
+    if kind == 1:       # around the threshold (25 / 26), around max_depth (25600), the largest payload (65535)
+        m = g.random((rows, cols)) < 0.03
+        k[m] = g.choice(np.array([1, 25, 26, 27, 25599, 25600, 25601, 40000, 65535]), int(m.sum()))
+    elif kind == 2:
+        k[:, g.integers(0, cols):] = 0
+        k[: g.integers(0, rows)] = 0
+    elif kind == 3 and rows > 40:
+        k[8:-8] = 0
+    return (k.astype(np.float32) / np.float32(256.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_16_bit_codes_against_oracle(seed, monkeypatch):
+    """The 16-bit form of X6 (k_pre_p<Q16OUT> -> k_fp_q, by default only on batches of about a thousand frames) forced onto
+    small random batches: frames on the 1/256 m grid with values at every edge of the code range, some batches with a frame off
+    the grid (the gated f32 rerun), both structuring elements, with and without the blur, plain and label-masked, through the
+    host entry point (synchronised hole-closure loop) and the device entry point."""
+    import torch
+    from oracle import oracle as O
+    monkeypatch.setenv("DCMT_Q16_MIN_WAVES", "0")
+    g = np.random.Generator(np.random.PCG64(7000 + seed))
+    for case in range(6):
+        rows, cols = int(g.integers(8, 180)), 2 * int(g.integers(4, 200))
+        batch = int(g.choice([8, 9, 16]))
+        k0 = ("as_compiled", "diamond")[g.integers(0, 2)]
+        blur = ("gaussian", "none")[g.integers(0, 2)]
+        labeled = g.random() < 0.3
+        frames = np.stack([_grid_frame(g, rows, cols) for _ in range(batch)])
+        if g.random() < 0.3:
+            f = int(g.integers(0, batch))
+            frames[f] = (frames[f] * np.float32(1.003)).astype(np.float32)      # one frame off the grid
+        what = f"seed {seed} case {case}: {rows}x{cols} b{batch} {k0} {blur} labeled{labeled}"
+        kw = dict(k0=k0, blur_type=blur, max_fill_iters=6)
+        op = O.default_params(k0=k0, blur=blur, max_fill_iters=6)
+        with api.Context(0, rows, cols, batch) as c:
+            if labeled:
+                lab, n = _labels(g, rows, cols)
+                got = c.complete(frames, api.make_params(**kw), labels=np.broadcast_to(lab, frames.shape), n_labels=n, allow_not_converged=True)
+                dev = None
+            else:
+                got = c.complete(frames, api.make_params(**kw), allow_not_converged=True)
+                dev = c.complete_dev(torch.from_numpy(frames).cuda(), None, api.make_params(spec_fill_iters=6, **kw))
+                torch.cuda.synchronize()
+                dev = dev.cpu().numpy()
+        for f in range(batch):
+            ref = O.interpolate_with_superpixels(frames[f], lab, n, op) if labeled else O.img_completion(frames[f], op)
+            assert_bit_equal(got[f], ref, what + f" frame {f} (host entry point)")
+            if dev is not None:
+                assert_bit_equal(dev[f], ref, what + f" frame {f} (device entry point)")
+
+
 def test_mixed_calls_on_one_context_keep_no_state():
     """One long-lived context, forty calls of every kind in random order and random sizes (host and device entry points, labels,
     normalise, uint16 ingest, projection, SLIC, stereo refinement): scratch reuse, table regrowth and leftovers of an earlier
