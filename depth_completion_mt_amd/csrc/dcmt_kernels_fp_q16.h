@@ -310,9 +310,11 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
                 const unsigned bo = u_row_ror8(w31b);
                 unsigned pa, sa, pb, sb;
                 u_row_scans4(umax2(e, od), umax2(w31b, bo), pa, sa, pb, sb);
-                const unsigned pxa = u_row_shr1(pa), sxa = u_row_shl1(sa), pxb = u_row_shr1(pb), sxb = u_row_shl1(sb);
-                sx = b_hi ? sxb : sxa; so = umax2(b_hi ? bo : od, sx);
-                px = b_lo ? pxb : pxa; pe = umax2(b_lo ? w31b : e, px);
+                // exclusive scans = the inclusive ones shifted by a lane; which register a lane hands on is chosen BEFORE the shift, at
+                // the source lane (lanes 0..6 feed the halo lanes 1..7, lane 7 feeds lane 8 of A; lanes 57..63 likewise): two shifts, not four
+                px = u_row_shr1(lane < 7 ? pb : pa); sx = u_row_shl1(lane > 56 ? sb : sa);
+                so = umax2(b_hi ? bo : od, sx);
+                pe = umax2(b_lo ? w31b : e, px);
             } else {
                 // (the fetches of lanes 0..7 and 56..63 wrap around the wave: their X7 is not exact, and nothing reads it)
                 unsigned pa, sa;
