@@ -228,11 +228,9 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     const bool warm = V > 0;
     unsigned xa0 = 0, xb0 = 0;                                       // cold start: 0 is the neutral element
     if (warm) { const Raw r = ld_row(0); xa0 = pack(r.e, r.o); xb0 = r.b; }
-    unsigned PFA[16], PFB[16], W2A[16], W6A[16], W2B[16], W6B[16], DL[8];
+    unsigned PFA[16], PFB[16], W2A[16], W6A[16], W2B[16], W6B[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) { PFA[q] = PFB[q] = 0; W2A[q] = W6A[q] = xa0; W2B[q] = W6B[q] = xb0; }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) DL[q] = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; if constexpr (BREG) dl_b[q][lb] = xb0; }
     constexpr int PFD = DCMT_FPQ_PFD;        // rows of load lookahead
@@ -341,22 +339,32 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
         pipe.template after_median<PP>(Q16::value(m & 0xffffu), Q16::value(m >> 16), u);
     };
 
-    for (int t0 = warm ? 16 : 0; t0 < FpP::LAG; t0 += 16) {
+    // steps 0..31 (16..31 after a warm start): fill only.  The last of them returns X7 row 0, which the post pipeline takes three times
+    // (its replicated rows -2 and -1, and row 0: post steps 0, 1, 2)
+    for (int t0 = warm ? 16 : 0; t0 < 32; t0 += 16) {
         static_for<0, 16>([&](auto P_) {
             constexpr int p = decltype(P_)::value;
-            DL[p & 7] = fill_step(P_, t0 + p);
+            const unsigned x7 = fill_step(P_, t0 + p);
+            if constexpr (p == 15) {
+                if (t0 == 16) {
+                    post_step(std::integral_constant<int, 0>{}, x7, 0);
+                    post_step(std::integral_constant<int, 1>{}, x7, 1);
+                    post_step(std::integral_constant<int, 2>{}, x7, 2);
+                }
+            }
         });
     }
-    DL[5] = DL[6] = DL[7];
-    const int nsteps = rows + 38;
-    for (int t0 = FpP::LAG; t0 < nsteps; t0 += 16) {
+    // steps 32..rows+34: post step u = t - 29 takes X7 row u - 2 = t - 31, the row this step's fill front end returns
+    const int nsteps = rows + 35;
+    for (int t0 = 32; t0 < nsteps; t0 += 16) {
         static_for<0, 16>([&](auto P_) {
             constexpr int p = decltype(P_)::value;
-            const int t = t0 + p, u = t - FpP::LAG;
-            DL[p & 7] = fill_step(P_, t);
-            post_step(std::integral_constant<int, (p & 7)>{}, DL[(p + 5) & 7], u);
-            if constexpr (p == 6) {
-                if (t0 == FpP::LAG && V > 0) {
+            const int t = t0 + p, u = t - 29;
+            const unsigned x7 = fill_step(P_, t);
+            post_step(std::integral_constant<int, ((p + 3) & 7)>{}, x7, u);
+            if constexpr (p == 3) {
+                // u == 6: output row 0 of the shifted frame (image row V) has just been stored; the V rows above it are equal
+                if (t0 == 32 && V > 0) {
                     FrameBuf top;
                     top.init(dst + fo, (size_t)V * cols);
                     const unsigned tbo = pipe.outlane ? pipe.ob : kDropOffset;

@@ -958,8 +958,8 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
 //     S' = lane >= 49 ? P_B : S_A,   P' = lane <= 14 ? P_B : P_A
 // -- the left halo sits in B in descending column order, so both halos need the same prefix scan.  Every one of the 64
 // lanes therefore gets its exact X7 value, and the post pipeline (PostPipe) runs on it in the
-// same step, 32 steps later than the fill front end (30 rows of fill latency + its own 2 rows
-// of replicate padding): step t feeds X7 row clamp(t - 34) to post step u = t - 32.
+// same step, 29 steps behind the fill front end (30 rows of fill latency + one step of skew; its own 2 rows of replicate
+// padding are the three post steps run at t = 31): step t feeds X7 row t - 31 to post step u = t - 29.
 //
 // The vertical 31-max of both registers is the doubling of k_fill_s; the two 15-step delays that
 // are only read once (the centre values and the B register's 16-row maxima) live in a
@@ -970,7 +970,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
 // cnt[1] > 0 are recomputed afterwards by k_fill_s / k_post_s (their only_if_holes modes).
 // ---------------------------------------------------------------------------------
 struct FpS {
-    static constexpr int LAG = 32;               // post step u = t - LAG
+    static constexpr int LAG = 29;               // post step u = t - LAG: it takes X7 row u - 2 = t - 31, which the fill front end returns in the same step
 };
 
 template <bool BLUR>
@@ -1041,11 +1041,9 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     // behind: every window maximum and every delay-line slot holds row V.
     const bool warm = V > 0;
     const float xa0 = warm ? ld_a(0) : NEG, xb0 = warm ? ld_b(0) : NEG;
-    float PFA[16], PFB[16], W2A[16], W6A[16], W2B[16], W6B[16], DL[8];
+    float PFA[16], PFB[16], W2A[16], W6A[16], W2B[16], W6B[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) { PFA[q] = PFB[q] = 0.f; W2A[q] = W6A[q] = xa0; W2B[q] = W6B[q] = xb0; }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) DL[q] = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { dl_c[q][lane] = xa0; dl_a[q][lane] = xa0; dl_b[q][lb] = xb0; }
 #ifndef DCMT_FP_PFD
@@ -1127,26 +1125,32 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         return x7;
     };
 
-    // steps 0..31 (16..31 after a warm start): fill only (X7 row 0 appears at t = 31)
-    for (int t0 = warm ? 16 : 0; t0 < FpS::LAG; t0 += 16) {
+    // steps 0..31 (16..31 after a warm start): fill only.  The last of them returns X7 row 0, which the post pipeline takes three times
+    // (its replicated rows -2 and -1, and row 0: post steps 0, 1, 2)
+    for (int t0 = warm ? 16 : 0; t0 < 32; t0 += 16) {
         static_for<0, 16>([&](auto P_) {
             constexpr int p = decltype(P_)::value;
-            DL[p & 7] = fill_step(P_, t0 + p);
+            const float x7 = fill_step(P_, t0 + p);
+            if constexpr (p == 15) {
+                if (t0 == 16) {
+                    pipe.template step<0>(x7, 0);
+                    pipe.template step<1>(x7, 1);
+                    pipe.template step<2>(x7, 2);
+                }
+            }
         });
     }
-    DL[5] = DL[6] = DL[7];                       // rows -2, -1 replicate row 0 (step 31 left X7 row 0 in DL[7])
-    // steps 32..rows+37: fill + post; post step u = t - 32 takes X7 row clamp(u - 2) = clamp(t - 34),
-    // which the fill front end produced 3 steps ago
-    const int nsteps = rows + 38;
-    for (int t0 = FpS::LAG; t0 < nsteps; t0 += 16) {
+    // steps 32..rows+34: fill + post; post step u = t - FpS::LAG takes X7 row u - 2 = t - 31, the row this step's fill front end returns
+    const int nsteps = rows + 35;
+    for (int t0 = 32; t0 < nsteps; t0 += 16) {
         static_for<0, 16>([&](auto P_) {
             constexpr int p = decltype(P_)::value;
             const int t = t0 + p, u = t - FpS::LAG;
-            DL[p & 7] = fill_step(P_, t);
-            pipe.template step<(p & 7)>(DL[(p + 5) & 7], u);
-            if constexpr (p == 6) {
+            const float x7 = fill_step(P_, t);
+            pipe.template step<((p + 3) & 7)>(x7, u);
+            if constexpr (p == 3) {
                 // u == 6: output row 0 of the shifted frame (image row V) has just been stored; the V rows above it are equal
-                if (t0 == FpS::LAG && V > 0) {
+                if (t0 == 32 && V > 0) {
                     FrameBuf top;
                     top.init(dst + fo, (size_t)V * cols);
                     const unsigned tb = pipe.outlane ? pipe.ob : kDropOffset;
