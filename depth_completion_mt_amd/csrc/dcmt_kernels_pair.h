@@ -141,8 +141,6 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     float OX[8], S1E[8];                         // as compiled: x2 of the odd column, x2 of the even column of the next lane
     F2 XR[8], A3[8];                             // diamond: x2 rows, horizontal 3-max rows
     F2 H4[8], HE[8], H7[8], E4[8], T7[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { OX[q] = NEG; S1E[q] = NEG; XR[q] = NEG2; A3[q] = NEG2; H4[q] = NEG2; HE[q] = POS2; H7[q] = NEG2; E4[q] = NEG2; T7[q] = NEG2; PF[q] = {0.f, 0.f}; }
 #ifndef DCMT_PAIR_PFD
 #define DCMT_PAIR_PFD 6
 #endif
@@ -151,16 +149,23 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     // ---- where the stream starts: below the leading empty rows (k_pre_s has the argument), or 18 rows above the band
     // START4 (the input is X4, only H5 runs): x5(m) reaches X4 rows m-3 .. m+3 and step i feeds X4 row i - 6 while finishing x5 row
     // i - 9, so the stream may start at step zv itself and its x5 rows are exact from S - 3 on.
+    // Warm start: if the rows above zv are not just empty but exactly 0.0 in the wave's columns (a KITTI frame's empty pixels are),
+    // every stage's rows above zv - 6 are 0.0 too (each depends on input rows at most 6 further down), so the stream starts AT zv
+    // with its rings holding those zeros -- exact from x5 row zv - 9 on -- instead of 24 rows earlier with cold rings.
     constexpr int DZ = START4 ? 0 : 18, DM = START4 ? -3 : 9;
     int S = 0;
+    bool warm0 = false;
     if (band > 0) S = max(r0 - 18, 0) & ~7;
     else {
         // 16-row chunks, two in flight: the scan is a chain of dependent round trips to memory, one per chunk
+        bool zeros = true;                                           // every chunk above zv held nothing but 0.0
         auto valid16 = [&](const F2 (&v)[16]) -> bool {
-            float m = fmax2(v[0].e, v[0].o);
+            float m = fmax2(v[0].e, v[0].o), mn = fmin2(v[0].e, v[0].o);
 #pragma unroll
-            for (int q = 1; q < 16; q += 1) m = fmax3(m, v[q].e, v[q].o);
-            return __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;
+            for (int q = 1; q < 16; q += 1) { m = fmax3(m, v[q].e, v[q].o); mn = fmin3(mn, v[q].e, v[q].o); }
+            const bool valid = __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;
+            if (!valid) zeros = zeros && __builtin_amdgcn_ballot_w64(m != 0.0f || mn != 0.0f) == 0ull;
+            return valid;
         };
         auto load16 = [&](F2 (&v)[16], int z) {
 #pragma unroll
@@ -180,9 +185,16 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             load16(va, z + 32);
             if (valid16(vb)) { zv = z + 16; break; }
         }
-        S = max(zv - DZ, 0) & ~7;
+        warm0 = !START4 && zeros && zv >= 32 && zv < r1;
+        S = warm0 ? zv : max(zv - DZ, 0) & ~7;
     }
-    const int m0 = max(S > 0 ? S + (band > 0 ? 9 : DM) : 0, r0);   // first x5 row this wave accounts for
+    const int m0 = warm0 ? S - 9 : max(S > 0 ? S + (band > 0 ? 9 : DM) : 0, r0);   // first x5 row this wave accounts for
+    {
+        const float ng = warm0 ? 0.0f : NEG, ps = warm0 ? 0.0f : POS;
+        const F2 ng2 = {ng, ng}, ps2 = {ps, ps};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { OX[q] = ng; S1E[q] = ng; XR[q] = ng2; A3[q] = ng2; H4[q] = ng2; HE[q] = ps2; H7[q] = ng2; E4[q] = ng2; T7[q] = ng2; PF[q] = {0.f, 0.f}; }
+    }
 
 #pragma unroll
     for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));
