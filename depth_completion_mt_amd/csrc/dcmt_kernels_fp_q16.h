@@ -19,9 +19,9 @@
 // a hole, unpacks the two halves and is k_fp_p's scheme on unsigned integers (0 is the neutral element; register B holds the
 // 30 halo columns unpacked, one per lane).
 //
-// X6U16 = false: X6 arrives as f32 (k_pre_p / k_pre_s as they are) and is converted while loading (exact for a conforming
-// frame).  What a frame that does NOT conform produces is garbage of the right shape; the caller must only use this kernel on
-// frames it knows to conform (dcmt.hip: the uint16 entry point with scale 1/256, or frames the conformance pass has cleared).
+// X6U16 = true: X6 arrives as the codes themselves (k_pre_p<Q16OUT>, which has checked every value it stored and raised a flag
+// otherwise -- dcmt.hip reruns the f32 kernels behind that flag, so what this kernel makes of a frame that is no grid is never
+// looked at).  X6U16 = false (X6 as f32, converted while loading) was the first stage of this work and is kept for experiments.
 #pragma once
 
 #include "dcmt_kernels_fp_pair.h"
