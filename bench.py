@@ -382,8 +382,9 @@ def load_profile_json(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=30,
+                    help="untimed steps first (a freshly started process needs ~20 steps of the 1024-frame step to reach its steady step time: tools/time_warmup.py)")
     ap.add_argument("--total-frames", type=int, default=1024, help="frames per step over ALL ranks, sharded per frame (BASELINE configs[4]: 1024)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank owns --batch frames per step")
     ap.add_argument("--batch", type=int, default=1024, help="--weak: frames per GPU per step")
