@@ -63,6 +63,7 @@ struct dcmt_ctx {
     int fp_pair = 0;                  // env DCMT_FP_PAIR=1: two columns per lane in H7..H11 (k_fp_p: 8 % fewer VALU instructions, but its ~200 VGPRs leave 2 waves per SIMD and it is slower)
     int fp_q16 = 1;                   // X6 as 16-bit codes + k_fp_q wherever the frames allow it (multiples of 1/256 m: checked on the device, the f32
                                       // kernels rerun behind a raised flag); env DCMT_FP_Q16=0 disables
+    int assume_filled = 1;            // k_fp_s / k_fp_q without the median >= thr select where the redo chain follows; env DCMT_ASSUME_FILLED=0 keeps it
     int q16_breg = 1;                 // k_fp_q with the halo columns in a second register (120 output columns per wave, 3 waves per SIMD); 0 = wider strip
                                       // overlap instead (88 output columns, 4 waves per SIMD: measured 2.5 % slower -- the kernel is bound by issue, not by
                                       // occupancy); env DCMT_Q16_BREG
@@ -326,14 +327,17 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const dim3 fpg = wave_grid(pstrips, nb, xm);
             // two columns per lane (k_fp_p) wherever a lane's 8-byte stores are aligned: even width, 8-byte aligned frames
             const bool fpp = ctx->fp_pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0);
+            // frames this kernel leaves with holes are recomputed by the redo chain below whenever that chain is enqueued (always on the host
+            // entry points, with spec_fill_iters >= 1 on the device ones): then the kernel may leave out the select that only such frames need
+            const bool filled = bl && ctx->assume_filled && (sync_loop || (p->spec_fill_iters >= 1 && p->max_fill_iters >= 1));
             const bool src16_q = d_src16 != nullptr;          // codes by construction: no rerun needed
             if (q16) {
                 const void* xq = ctx->x6q + f0 * fe;
-#define DCMT_FPQ(BL, BREG) { const int qstrips = (cols + FpQ::vw<BREG>() - 1) / FpQ::vw<BREG>(); \
-                    hipLaunchKernelGGL((k_fp_q<BL, true, BREG>), wave_grid(qstrips, nb, xm), b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, \
+#define DCMT_FPQ(BL, BREG, FILLED) { const int qstrips = (cols + FpQ::vw<BREG>() - 1) / FpQ::vw<BREG>(); \
+                    hipLaunchKernelGGL((k_fp_q<BL, true, BREG, FILLED>), wave_grid(qstrips, nb, xm), b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, \
                                        p->max_depth, p->valid_thresh, (const int*)tc, bands); }
-                if (ctx->q16_breg) { if (bl) DCMT_FPQ(true, true) else DCMT_FPQ(false, true) }
-                else               { if (bl) DCMT_FPQ(true, false) else DCMT_FPQ(false, false) }
+                if (ctx->q16_breg) { if (filled) DCMT_FPQ(true, true, true) else if (bl) DCMT_FPQ(true, true, false) else DCMT_FPQ(false, true, false) }
+                else               { if (bl) DCMT_FPQ(true, false, false) else DCMT_FPQ(false, false, false) }
 #undef DCMT_FPQ
                 if (!src16_q) {
                     // frames that are no multiples of 1/256 m: both f32 kernels again, gated on the flag the attempt raised (they return at once otherwise)
@@ -341,7 +345,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     const uint16_t* src16 = nullptr; const float* cf = nullptr; const hipStream_t ps = st;
                     const float* src = (d_x4 ? d_x4 : d_src) + f0 * fe;
                     if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)ctx->q16_bad) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)ctx->q16_bad)
-                    if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
+                    if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
+                    else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
                     else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
                 }
             }
@@ -351,6 +356,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 if (bl) hipLaunchKernelGGL((k_fp_p<true>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
                 else    hipLaunchKernelGGL((k_fp_p<false>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
             }
+            else if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
             else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
             else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
 #undef DCMT_PREP
@@ -726,6 +732,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_FP_Q16"); if (e) ctx->fp_q16 = std::atoi(e); }
     { const char* e = std::getenv("DCMT_Q16_MIN_WAVES"); if (e) ctx->q16_min_waves = std::atoi(e); }
     { const char* e = std::getenv("DCMT_Q16_BREG"); if (e) ctx->q16_breg = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_ASSUME_FILLED"); if (e) ctx->assume_filled = std::atoi(e); }
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }

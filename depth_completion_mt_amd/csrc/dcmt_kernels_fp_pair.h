@@ -85,7 +85,7 @@ __device__ __forceinline__ void sort5_pair(F2 x, float (&se)[5], float (&so)[5])
 
 // PostPipe (dcmt_kernels_fused.h) for two columns per lane, MODE 11 only.  Step u takes X7 row clamp(u - 2), finishes the
 // median of image row u - 4 and the output of image row u - 6.
-template <bool BLUR, int HALO = FpP::H>
+template <bool BLUR, int HALO = FpP::H, bool FILLED = false>     // FILLED: see PostPipe
 struct PostPipeP {
     MedianColumn mce, mco;
     F2 G1[8], MR[8];
@@ -148,8 +148,8 @@ struct PostPipeP {
                     const F2 g0 = G1[(PP + 2) & 7];
                     const float ae = gauss_taps(g0.e, __fadd_rn(u1.e, d1.e), __fadd_rn(u2.e, d2.e));
                     const float ao = gauss_taps(g0.o, __fadd_rn(u1.o, d1.o), __fadd_rn(u2.o, d2.o));
-                    if (mo_.e >= thr) val.e = ae;                        // LO :184
-                    if (mo_.o >= thr) val.o = ao;
+                    if (FILLED || mo_.e >= thr) val.e = ae;              // LO :184
+                    if (FILLED || mo_.o >= thr) val.o = ao;
                 }
                 val = {invert_valid(val.e, max_depth, thr), invert_valid(val.o, max_depth, thr)};   // LO :191-202
                 st2(of, outlane ? ob : kDropOffset, o, cols, val);

@@ -152,7 +152,7 @@ struct FpQ {
     template <bool BREG> static constexpr int halo() { return BREG ? FpP::H : 16 + FpP::H; }
     template <bool BREG> static constexpr int vw() { return 128 - 2 * halo<BREG>(); }
 };
-template <bool BLUR, bool X6U16, bool BREG = true>
+template <bool BLUR, bool X6U16, bool BREG = true, bool FILLED = false>
 __global__ __launch_bounds__(256)
 #if DCMT_FPQ_WAVES
 __attribute__((amdgpu_waves_per_eu(DCMT_FPQ_WAVES, DCMT_FPQ_WAVES)))
@@ -220,7 +220,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     unsigned (*dl_b)[32] = reinterpret_cast<unsigned (*)[32]>(sd + 16 * 128);
     const int lb = lane < 16 ? lane : (lane >= 48 ? lane - 32 : 0);
 
-    PostPipeP<BLUR, HALO> pipe;                                      // only its after_median() half is used
+    PostPipeP<BLUR, HALO, FILLED> pipe;                                      // only its after_median() half is used
     pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
     MedianColumnQ mc;
     mc.init();

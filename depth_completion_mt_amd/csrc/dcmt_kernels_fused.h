@@ -688,7 +688,10 @@ __device__ __forceinline__ float gauss_taps(float c, float s1, float s2)
 //
 // Step u takes X7 row clamp(u - 2) (replicate rows), finishes the median of image row u - 4
 // and the output of image row u - 6.
-template <int MODE, bool BLUR>
+// FILLED: the caller guarantees that every frame whose X7 still holds a hole is recomputed afterwards (k_fp_s followed by the
+// redo chain).  A frame without holes has every median >= thr, so the masked select of LO :184 always takes the blurred value
+// and its compare + select (two of the slow instructions per pixel) are left out; what a frame WITH holes gets is overwritten.
+template <int MODE, bool BLUR, bool FILLED = false>
 struct PostPipe {
     static constexpr bool do_blur = BLUR && MODE >= 10;
     MedianColumn mc;         // the vertical half of the median (dcmt_median.h)
@@ -750,7 +753,7 @@ struct PostPipe {
                 float val = mo;
                 if constexpr (do_blur) {
                     const float acc = gauss_taps(G1[(PP + 2) & 7], __fadd_rn(u1, d1), __fadd_rn(u2, d2));
-                    if (mo >= thr) val = acc;                           // LO :184
+                    if (FILLED || mo >= thr) val = acc;                 // LO :184
                 }
                 if constexpr (MODE >= 11) val = invert_valid(val, max_depth, thr);  // LO :191-202
                 of.st(outlane ? ob : kDropOffset, o, cols, val);     // every lane stores; halo lanes aim past the buffer (dropped)
@@ -973,7 +976,7 @@ struct FpS {
     static constexpr int LAG = 29;               // post step u = t - LAG: it takes X7 row u - 2 = t - 31, which the fill front end returns in the same step
 };
 
-template <bool BLUR>
+template <bool BLUR, bool FILLED = false>
 __global__ __launch_bounds__(256)
 void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
             int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb,
@@ -1032,7 +1035,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     float (*dl_b)[32] = reinterpret_cast<float (*)[32]>(s_delay[wave] + 16 * 128);
     const int lb = lane <= 14 ? lane : (lane >= 48 ? lane - 32 : 15);   // B's live lanes 0..14, 48..63 -> words 0..14, 16..31; the dead lanes share word 15
 
-    PostPipe<11, BLUR> pipe;
+    PostPipe<11, BLUR, FILLED> pipe;
     pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
 
     constexpr float NEG = -FLT_MAX;
