@@ -85,7 +85,10 @@ __device__ __forceinline__ void sort5_pair(F2 x, float (&se)[5], float (&so)[5])
 
 // PostPipe (dcmt_kernels_fused.h) for two columns per lane, MODE 11 only.  Step u takes X7 row clamp(u - 2), finishes the
 // median of image row u - 4 and the output of image row u - 6.
-template <bool BLUR, int HALO = FpP::H, bool FILLED = false>     // FILLED: see PostPipe
+// FILLED: see PostPipe.  GRID (k_fp_q, with FILLED): every median is a multiple of 1/256 and >= thr = 0.1, i.e. >= 26/256 = 0.1015625;
+// the blurred value is a convex combination of such medians evaluated with a dozen roundings of 2^-24 each, so it stays above
+// 0.10156 > thr and the final invert (LO :191-202) is `max_depth - value` without its compare and select.
+template <bool BLUR, int HALO = FpP::H, bool FILLED = false, bool GRID = false>
 struct PostPipeP {
     MedianColumn mce, mco;
     F2 G1[8], MR[8];
@@ -151,7 +154,8 @@ struct PostPipeP {
                     if (FILLED || mo_.e >= thr) val.e = ae;              // LO :184
                     if (FILLED || mo_.o >= thr) val.o = ao;
                 }
-                val = {invert_valid(val.e, max_depth, thr), invert_valid(val.o, max_depth, thr)};   // LO :191-202
+                if constexpr (BLUR && FILLED && GRID) val = {__fsub_rn(max_depth, val.e), __fsub_rn(max_depth, val.o)};
+                else val = {invert_valid(val.e, max_depth, thr), invert_valid(val.o, max_depth, thr)};   // LO :191-202
                 st2(of, outlane ? ob : kDropOffset, o, cols, val);
                 last_out = val;
             };

@@ -220,7 +220,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     unsigned (*dl_b)[32] = reinterpret_cast<unsigned (*)[32]>(sd + 16 * 128);
     const int lb = lane < 16 ? lane : (lane >= 48 ? lane - 32 : 0);
 
-    PostPipeP<BLUR, HALO, FILLED> pipe;                                      // only its after_median() half is used
+    PostPipeP<BLUR, HALO, FILLED, FILLED> pipe;                      // codes are grid values                                      // only its after_median() half is used
     pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
     MedianColumnQ mc;
     mc.init();
