@@ -53,7 +53,10 @@ __device__ __forceinline__ void u_row_scans4(unsigned a, unsigned b, unsigned& p
                    "v_max_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t" \
                    "v_max_u32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
                    "v_max_u32_dpp %3, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"
-    asm("s_nop 1\n\t" DCMT_U4(1) DCMT_U4(2) DCMT_U4(4) DCMT_U4(8) : "+v"(pa), "+v"(sa), "+v"(pb), "+v"(sb));
+    // (b's scans are only looked at in lanes 0..7 (prefix) and 56..63 (suffix): eight lanes each, three steps)
+    asm("s_nop 1\n\t" DCMT_U4(1) DCMT_U4(2) DCMT_U4(4)
+        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_u32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(pa), "+v"(sa), "+v"(pb), "+v"(sb));
 #undef DCMT_U4
 }
 
