@@ -95,7 +95,7 @@ def _grid_frame(g, rows, cols):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_16_bit_codes_against_oracle(seed, monkeypatch):
-    """The 16-bit form of X6 (k_pre_p<Q16OUT> -> k_fp_q, by default only on batches of about a thousand frames) forced onto
+    """The 16-bit form of X6 (k_pre_p<Q16OUT> -> k_fp_q, by default only on batches of more than about six hundred frames) forced onto
     small random batches: frames on the 1/256 m grid with values at every edge of the code range, some batches with a frame off
     the grid (the gated f32 rerun), both structuring elements, with and without the blur, plain and label-masked, through the
     host entry point (synchronised hole-closure loop) and the device entry point."""
