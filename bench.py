@@ -14,7 +14,7 @@ data path; torch.distributed carries the barriers and the max-over-ranks of the 
 Prints ONE JSON line (rank 0).  value = frames/s over all ranks.
   roofline      whole cascade of one step on one GPU: algorithmic bytes (8 B/px: sparse f32 in + dense f32 out, intermediates
                 count zero) / mean GPU time per step, HIP events on the launch stream; .per_kernel = the library's own events
-                around k_pre / k_fp_s (dcmt_set_kernel_timing) in an extra untimed pass; .valu = the instruction-issue
+                around its two kernels (dcmt_set_kernel_timing; named by dcmt_last_path) in an extra untimed pass; .valu = the instruction-issue
                 side (what actually binds both kernels), from the SQ counters of profiles/valu_latest.json; .traffic from the
                 PMC passes of profiles/traffic_latest.json (both written by tools/collect_profiles.sh on the builder's box).
   configs       (rank 0, N = 1) the other BASELINE configs, each with its own roofline: [1] batch = 1 streamed,
@@ -139,6 +139,18 @@ def timed(torch, fn, n, stream):
     return e0.elapsed_time(e1) / n
 
 
+def verify_against_oracle(np, out_frames, in_frames, what: str):
+    """Output frames of the TIMED buffers against the CPU oracle on the same inputs, bit for bit (the oracle is the checker here,
+    never the thing measured).  Returns None if all agree, else a description of the first difference."""
+    from oracle import oracle as O          # checker only
+    for k, (got, x) in enumerate(zip(out_frames, in_frames)):
+        want = O.img_completion(np.ascontiguousarray(x))
+        if not np.array_equal(np.ascontiguousarray(got).view(np.uint32), want.view(np.uint32)):
+            bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+            return f"{what}: checked frame {k} differs from the oracle in {bad} pixels"
+    return None
+
+
 def hbm_roofline(bytes_per_step: float, ms: float) -> dict:
     a = bytes_per_step / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
@@ -160,14 +172,14 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
         k[0] += 1
     ms = timed(torch, one, 200, stream)
     out["1"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, batch=1 streamed (one dcmt_complete_f32_dev call per frame, one stream)",
-                "value": 1e3 / ms, "unit": "frames/s", "us_per_frame": ms * 1e3, "roofline": hbm_roofline(BYTES_PER_FRAME, ms)}
+                "value": 1e3 / ms, "unit": "frames/s", "us_per_frame": ms * 1e3, "kernels": c1.last_path(), "roofline": hbm_roofline(BYTES_PER_FRAME, ms)}
     c1.close()
     # [4] at 8 GPUs = 128 frames per GPU per step: that per-GPU workload on this GPU
     b128 = min(128, B)
     c4 = Context(local_rank, ROWS, COLS, b128)
     ms = timed(torch, lambda: c4.complete_dev(d_src[:b128], d_dst[:b128], params, stream=stream.cuda_stream), steps, stream)
     out["4_per_gpu_share"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {b128} frames per step (the per-GPU shard of 1024 frames on 8 GPUs)",
-                              "value": b128 * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(b128 * BYTES_PER_FRAME, ms)}
+                              "value": b128 * 1e3 / ms, "unit": "frames/s", "kernels": c4.last_path(), "roofline": hbm_roofline(b128 * BYTES_PER_FRAME, ms)}
     c4.close()
     # the same step on frames that are NOT multiples of 1/256 m (every depth scaled by 1.001): the 16-bit form of X6 does not apply, the
     # first call pays the attempt and the f32 rerun, the following ones go straight to the f32 kernels (k_pre_p -> k_fp_s) -- the
@@ -180,8 +192,19 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
     ms = timed(torch, lambda: cg.complete_dev(d_off, d_dst, params, stream=stream.cuda_stream), steps, stream)
     out["4_off_grid_f32"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {B} frames per step whose depths are no multiples of 1/256 m: f32 kernels throughout (X6 as f32)",
                              "value": B * 1e3 / ms, "unit": "frames/s", "roofline": hbm_roofline(B * BYTES_PER_FRAME, ms)}
+    out["4_off_grid_f32"]["kernels"] = cg.last_path()
+    # frames that are valid from row 0 on (the lower half of every frame twice): nothing for the leading-row scan of k_pre_p and the
+    # top-zone skip of k_fp_* to leave out -- what the headline owes to the generator's empty upper third
+    d_full = torch.cat([d_src[:, ROWS // 2:], d_src[:, ROWS // 2:]], dim=1).contiguous()
+    for _ in range(2):
+        cg.complete_dev(d_full, d_dst, params, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+    ms = timed(torch, lambda: cg.complete_dev(d_full, d_dst, params, stream=stream.cuda_stream), steps, stream)
+    it_full, st_full = cg.last_fill_iters(B)
+    out["4_dense_from_row_0"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {B} frames per step, every frame valid from row 0 on (its lower half stacked twice: ~7 % valid, no empty upper third)",
+                                 "value": B * 1e3 / ms, "unit": "frames/s", "converged": st_full == 0, "kernels": cg.last_path(), "roofline": hbm_roofline(B * BYTES_PER_FRAME, ms)}
     cg.close()
-    del d_off
+    del d_off, d_full
     # the same 1024-frame step as four parts of 256 frames in flight on four streams, after the GPU has been busy for a while
     if B >= 1024:
         n4 = B // 4
@@ -218,8 +241,8 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
         kt = c.last_kernel_times()
         iters, st = c.last_fill_iters(Bl)
         out[key] = {"workload": f"{name} interpolate_with_superpixels, {cols}x{rows} f32 + int32 labels ({nl} labels), device-resident batch of {Bl}",
-                    "value": Bl * 1e3 / ms, "unit": "frames/s", "converged": st == 0,
-                    "roofline": dict(hbm_roofline(Bl * rows * cols * 12, ms), per_kernel_ms={"label_stage": kt["front"], "k_pre": kt["k_pre"], "k_fp_s": kt["k_fp_s"]})}
+                    "value": Bl * 1e3 / ms, "unit": "frames/s", "converged": st == 0, "kernels": c.last_path(),
+                    "roofline": dict(hbm_roofline(Bl * rows * cols * 12, ms), per_kernel_ms={"label_stage": kt["front"], "k_pre": kt["k_pre"], "k_fp": kt["k_fp"]})}
         c.close()
         del d, dl, o
         # the same at 1024 frames per step (the batch the headline is quoted on: 256 frames are 1.4 rounds of k_fp_s waves)
@@ -481,11 +504,15 @@ def main():
         it_k, st_k = c.last_fill_iters(e - b)
         iters += list(it_k)
         st = st if st_k == L.OK else st_k
-    failed, elapsed, gpu_ms_per_step = all_reduce_max(dist, [0.0 if st == L.OK else 1.0, elapsed, gpu_ms_per_step], device="cuda")
-    if failed:
+    # ... and what was timed must be RIGHT: frames of the timed output buffer (first, middle, last of this rank's shard) against the oracle
+    check = sorted({0, B // 2, B - 1})
+    mismatch = verify_against_oracle(np, [d_dst[i].cpu().numpy() for i in check], [host[i % uniq] for i in check], f"rank {rank}")
+    failed, wrong, elapsed, gpu_ms_per_step = all_reduce_max(dist, [0.0 if st == L.OK else 1.0, 0.0 if mismatch is None else 1.0, elapsed, gpu_ms_per_step], device="cuda")
+    if failed or wrong:
         if dist is not None:
             dist.destroy_process_group()
-        raise SystemExit("a frame needed more hole-closure applications than were enqueued: result invalid")
+        raise SystemExit(mismatch or ("a rank's timed output differs from the oracle: result invalid" if wrong else
+                                      "a frame needed more hole-closure applications than were enqueued: result invalid"))
 
     if rank == 0:
         # the same frames through ONE context on one stream (what a single call gives), and its live per-kernel split: untimed
@@ -500,17 +527,20 @@ def main():
             t = ctx.last_kernel_times()
             kt = [a + b / nk for a, b in zip(kt, (t["front"], t["k_pre"], t["k_fp_s"], t["behind"]))]
         ctx.set_kernel_timing(False)
+        path = ctx.last_path()                      # e.g. "k_pre_p<Q16OUT> + k_fp_q"
+        k_pre_name, k_fp_name = (path.split(" + ") + ["?"])[:2] if " + " in path else (path, "?")
         ctx.close()
         roof = hbm_roofline(B * BYTES_PER_FRAME, gpu_ms_per_step)
-        roof["kernel"] = ("whole cascade per step = k_pre_p + k_fp_q (the frames are multiples of 1/256 m, the KITTI depth format: X6 crosses HBM as 16-bit codes; "
+        roof["kernel"] = (f"whole cascade per step = {path} (on frames that are multiples of 1/256 m, the KITTI depth format, X6 crosses HBM as 16-bit codes; "
                           "+ the gated f32 rerun and 3 redo launches, which return at once) of every part, HIP events on the launch streams "
                           "around the K timed steps (first start to last end); with more than one part the kernels of different parts overlap, so the per-kernel "
                           "durations of a profile add up to more than the step; per_kernel and single_context: the same frames through ONE context on one stream "
                           "(the library's own events, dcmt_set_kernel_timing, 5 extra steps); rocprofv3 averages of that single-context step in profiles/")
         roof["single_context"] = dict(hbm_roofline(B * BYTES_PER_FRAME, one_ms), value=B * 1e3 / one_ms, unit="frames/s",
                                       note="one dcmt_complete_f32_dev call per step on one stream: the kernels run one after the other")
-        roof["per_kernel"] = {"k_pre": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
-                              "k_fp_s": dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="the H7..H11 kernel (k_fp_q on grid frames, k_fp_s otherwise) and the gated rerun launches behind it: reads X6, writes the dense frame"),
+        roof["kernels"] = path
+        roof["per_kernel"] = {k_pre_name: dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[1]), ms=kt[1], note="H2..H6: reads the sparse frame, writes X6 (algorithmic bytes of this kernel alone: 8 B/px)"),
+                              k_fp_name: dict(hbm_roofline(B * ROWS * COLS * 4 * 2, kt[2]), ms=kt[2], note="H7..H11 (and the gated rerun launches behind it, which return at once): reads X6, writes the dense frame"),
                               "redo_launches_ms": kt[3]}
         tr = load_profile_json("traffic_latest.json")
         roof["traffic"] = tr.get("hbm_bytes_per_step") if tr else None
@@ -529,7 +559,10 @@ def main():
                             "frac_of_issue": tot_issue / gpu_ms_per_step,
                             "peak": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz; min/max/med3/cmp/cndmask/DPP issue at ~4.4 cycles per wave64 instruction (tools/issue_probe.hip)",
                             "source": "profiles/valu_latest.json: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU pass of this step on the builder's box"}
-            roof["limiter"] = "valu-issue" if roof["valu"]["frac_of_issue"] > 0.6 else "mixed"
+            roof["valu_frac"] = roof["valu"]["frac_of_issue"]     # share of the step's GPU time the SIMDs spend issuing VALU instructions
+            roof["limiter"] = "valu-issue" if roof["valu_frac"] > 0.6 else "mixed"
+            roof["bound_note"] = ("bound = the roofline the PATH is priced against (stencils at 8 algorithmic B/px: HBM; the contract's enum); "
+                                  "limiter = what the kernels are limited by TODAY (valu_frac of the step is VALU issue time)")
         line = {
             "metric": METRIC, "value": total * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
@@ -543,6 +576,8 @@ def main():
                        "contexts_per_gpu": parts, "frames_per_context": [e - b for b, e in bounds],
                        "in_flight": "one call per context and step, one stream per context, joined only at the ends of the timed region"},
             "roofline": roof,
+            "verified": True,
+            "verified_how": f"frames {check} of the timed output buffer (every rank: first, middle, last of its shard) bit-identical to the CPU oracle on the same inputs",
             "fill_iters_max": max(iters),
         }
         if world == 1 and not args.no_configs:

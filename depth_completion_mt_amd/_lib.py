@@ -28,7 +28,7 @@ EXPORTS = (
     "dcmt_complete_labeled_f32_dev", "dcmt_complete_u16_dev", "dcmt_last_fill_iters", "dcmt_last_holes_after_extend",
     "dcmt_strerror", "dcmt_last_hip_error", "dcmt_version", "dcmt_project_points_dev", "dcmt_set_kernel_timing", "dcmt_last_kernel_times",
     "dcmt_slic_num_centers", "dcmt_slic_labels_dev", "dcmt_default_stereo_params", "dcmt_stereo_refine_dev",
-    "dcmt_project_points", "dcmt_slic_labels", "dcmt_stereo_refine",
+    "dcmt_project_points", "dcmt_slic_labels", "dcmt_stereo_refine", "dcmt_last_path",
 )
 
 
@@ -128,6 +128,8 @@ def lib() -> ctypes.CDLL:
         L.dcmt_strerror.argtypes = [i]
         L.dcmt_strerror.restype = ctypes.c_char_p
         L.dcmt_last_hip_error.argtypes = [vp]
+        L.dcmt_last_path.argtypes = [vp]
+        L.dcmt_last_path.restype = ctypes.c_char_p
         L.dcmt_set_kernel_timing.argtypes = [vp, i]
         L.dcmt_last_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.dcmt_version.argtypes = []

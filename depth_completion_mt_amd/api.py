@@ -47,7 +47,7 @@ def make_params(k0="as_compiled", blur_type: str = "gaussian", stop_after: int =
     p.stop_after = int(stop_after)
     p.max_fill_iters = int(max_fill_iters)
     p.spec_fill_iters = int(spec_fill_iters)
-    p.verbose = int(bool(verbose))
+    p.verbose = int(verbose)
     p.max_depth = float(max_depth)
     p.valid_thresh = float(valid_thresh)
     p.flags = (L.FLAG_FORCE_STAGED if force_staged else 0) | (L.FLAG_FORCE_FUSED if force_fused else 0)
@@ -244,7 +244,11 @@ class Context:
         st = L.lib().dcmt_last_kernel_times(self._h, ms)
         if st != L.OK:
             raise DcmtError(st, "dcmt_last_kernel_times")
-        return {"front": ms[0], "k_pre": ms[1], "k_fp_s": ms[2], "behind": ms[3]}
+        return {"front": ms[0], "k_pre": ms[1], "k_fp": ms[2], "k_fp_s": ms[2], "behind": ms[3]}
+
+    def last_path(self) -> str:
+        """The kernels the last cascade call dispatched (dcmt_last_path)."""
+        return L.lib().dcmt_last_path(self._h).decode()
 
     def last_holes_after_extend(self, n: int):
         out = (ctypes.c_int * n)()

@@ -49,6 +49,7 @@ struct dcmt_ctx {
     int last_apps_launched = 0;       // loop applications (app >= 1) enqueued
     int last_has_loop = 0;            // the call went at least through H8
     int last_hip_error = 0;
+    char last_path[160] = "";         // dcmt_last_path: the kernels the last call dispatched
     int timing = 0;                   // dcmt_set_kernel_timing: events around the kernel groups of the streaming path
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int tev_valid = 0;                // the last call recorded all five
@@ -154,6 +155,20 @@ int check_params(const dcmt_ctx* ctx, const void* a, const void* b, int rows, in
     if (p->stop_after < (norm ? DCMT_STAGE_NORMALIZE : DCMT_STAGE_INVERT) || p->stop_after > DCMT_STAGE_FINAL) return DCMT_E_INVALID;
     if (norm && !(finite_bits(p->norm_lo) && finite_bits(p->norm_hi))) return DCMT_E_INVALID;
     if (k0_bits(p->k0) == 0) return DCMT_E_INVALID;
+    return DCMT_OK;
+}
+
+// Scratch only one of the paths uses is allocated by the first call that takes that path (never again afterwards): the column
+// statistics of the staged tile kernels, the 16-bit plane of k_pre_p<Q16OUT> -> k_fp_q.
+int ensure_colstat(dcmt_ctx* ctx)
+{
+    if (!ctx->colstat)
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)ctx->max_cols * ((ctx->max_rows + FTH_FEW - 1) / FTH_FEW) * ctx->max_batch));
+    return DCMT_OK;
+}
+int ensure_x6q(dcmt_ctx* ctx)
+{
+    if (!ctx->x6q) DCMT_HIP(ctx, hipMalloc((void**)&ctx->x6q, sizeof(unsigned short) * ctx->frame_elems * (size_t)ctx->max_batch + 16));
     return DCMT_OK;
 }
 
@@ -300,8 +315,12 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                                        rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } }
             // 16-bit X6 (k_pre_p<Q16OUT> -> k_fp_q): the whole chain in table mode, two columns per lane, the reference's constants, no
             // normalisation in front (normalised depths are no multiples of 1/256)
+            // in place (or overlapping) f32 calls never take the 16-bit attempt: k_fp_q writes dst BEFORE the gated f32 rerun would read src again
+            // (the f32 kernels alone are alias-safe: src is only read by k_pre into ctx scratch, dst is written last)
+            const bool src_dst_overlap = !src16 && (uintptr_t)src < (uintptr_t)(dst + (size_t)nb * fe) && (uintptr_t)dst < (uintptr_t)(src + (size_t)nb * fe);
             q16 = q16_try && (long long)nb * ((cols + FpP::VW - 1) / FpP::VW) >= ctx->q16_min_waves && pair && tc && !cf && Q16::params_ok(p->max_depth, p->valid_thresh) && (uintptr_t)dst % 8 == 0 &&
-                  (!src16 || in_scale == 0.00390625f);
+                  (!src16 || in_scale == 0.00390625f) && !src_dst_overlap;
+            if (q16) { const int erc = ensure_x6q(ctx); if (erc != DCMT_OK) return erc; }
             float* x6q = reinterpret_cast<float*>(ctx->x6q + f0 * fe);
             if (q16) {
                 DCMT_HIP(ctx, hipMemsetAsync(ctx->q16_bad, 0, sizeof(int), ps));
@@ -315,6 +334,9 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
 #undef DCMT_PRE
             DCMT_HIP(ctx, hipGetLastError());
             stamp(2);
+            std::snprintf(ctx->last_path, sizeof ctx->last_path, "%s%s%s", d_x4 ? "k_label_bbox + k_label_stage + " : "",
+                          q16 ? (src16 ? "k_pre_p<U16,Q16OUT>" : "k_pre_p<Q16OUT>") : pair ? (d_x4 ? "k_pre_p<START4>" : src16 ? "k_pre_p<U16>" : cf ? "k_pre_p<NORM>" : "k_pre_p") : "k_pre_s",
+                          bands > 1 ? " (row bands)" : "");
             if (stop == DCMT_STAGE_EXTEND) continue;
         }
         const int fstrips = (cols + FillS::VW - 1) / FillS::VW;
@@ -362,6 +384,8 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
 #undef DCMT_PREP
             DCMT_HIP(ctx, hipGetLastError());
             stamp(3);
+            { const size_t n_ = std::strlen(ctx->last_path);
+              std::snprintf(ctx->last_path + n_, sizeof ctx->last_path - n_, " + %s", q16 ? "k_fp_q" : fpp ? "k_fp_p" : "k_fp_s"); }
             ctx->last_has_loop = 1;
             const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);
             if (n_redo > 0) {
@@ -546,6 +570,8 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
     ctx->last_apps_launched = 0;
     ctx->last_has_loop = 0;
 
+    { const int erc = ensure_colstat(ctx); if (erc != DCMT_OK) return erc; }
+    std::snprintf(ctx->last_path, sizeof ctx->last_path, "%s + k_fill31_v1 + k_post_v1 (staged tile kernels)", (d_labels && use_superpixel) ? "k_pre_labeled_v1" : "k_pre_v1");
     const int dump = stop <= DCMT_STAGE_CLOSE5 ? stop : 0;
     int stat_rows = (int)grid.y;                   // tile rows of the kernel that writes the column statistics
     if (d_labels && use_superpixel && few) {
@@ -621,7 +647,18 @@ int host_call(dcmt_ctx* ctx, const float* src, size_t srs, size_t sfs, const int
     if (rc != DCMT_OK) return rc;
     hipStream_t st = ctx->own_stream;
     const size_t row_b = sizeof(float) * (size_t)cols, frame_b = row_b * rows;
-    if (p->verbose) std::printf("NUMERO ROWS, COLS: %d %d\n", rows, cols);   // LO :29
+    if (p->verbose == 1) {
+        // what img_completion prints before it starts (LO :29, :41-50): the dimensions and the largest input value (start value 0.0, :22)
+        std::printf("NUMERO ROWS, COLS: %d %d\n", rows, cols);
+        for (int f = 0; f < batch; ++f) {
+            float mx = 0.0f;
+            for (int r = 0; r < rows; ++r) {
+                const float* row = reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + f * sfs + r * srs);
+                for (int c = 0; c < cols; ++c) mx = row[c] > mx ? row[c] : mx;
+            }
+            std::printf("max range is%g\n", (double)mx);               // operator<<(float): six significant digits, as %g
+        }
+    }
     for (int f = 0; f < batch; ++f) {
         if (srs == row_b)      // contiguous rows (the usual cv::Mat): one linear copy instead of a pitched one
             DCMT_HIP(ctx, hipMemcpyAsync((char*)ctx->d_in + f * frame_b, (const char*)src + f * sfs, frame_b, hipMemcpyHostToDevice, st));
@@ -746,9 +783,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->x5, plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[0], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->colstat, sizeof(int) * 2 * (size_t)max_cols * ((max_rows + FTH_FEW - 1) / FTH_FEW) * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->x6q, plane / 2 + 16) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->q16_bad, 256) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->q16_seen, 64, hipHostMallocMapped) != hipSuccess) return fail(DCMT_E_NOMEM);
     *ctx->q16_seen = 0;
@@ -1077,6 +1112,8 @@ int dcmt_last_holes_after_extend(dcmt_ctx* ctx, int* out, int n)
 }
 
 int dcmt_last_hip_error(const dcmt_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+const char* dcmt_last_path(const dcmt_ctx* ctx) { return ctx ? ctx->last_path : ""; }
 
 int dcmt_set_kernel_timing(dcmt_ctx* ctx, int on)
 {

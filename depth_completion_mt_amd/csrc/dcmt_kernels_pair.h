@@ -160,11 +160,14 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
         // 16-row chunks, two in flight: the scan is a chain of dependent round trips to memory, one per chunk
         bool zeros = true;                                           // every chunk above zv held nothing but 0.0
         auto valid16 = [&](const F2 (&v)[16]) -> bool {
-            float m = fmax2(v[0].e, v[0].o), mn = fmin2(v[0].e, v[0].o);
+            // the bit patterns are OR-ed (v_or3_b32): "exactly +0.0 everywhere" is a statement about bits -- rows holding a -0.0 take the
+            // cold start (the warm start would seed the rings with +0.0)
+            float m = fmax2(v[0].e, v[0].o);
+            unsigned ob = __builtin_bit_cast(unsigned, v[0].e) | __builtin_bit_cast(unsigned, v[0].o);
 #pragma unroll
-            for (int q = 1; q < 16; q += 1) { m = fmax3(m, v[q].e, v[q].o); mn = fmin3(mn, v[q].e, v[q].o); }
+            for (int q = 1; q < 16; q += 1) { m = fmax3(m, v[q].e, v[q].o); ob = ob | __builtin_bit_cast(unsigned, v[q].e) | __builtin_bit_cast(unsigned, v[q].o); }
             const bool valid = __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;
-            if (!valid) zeros = zeros && __builtin_amdgcn_ballot_w64(m != 0.0f || mn != 0.0f) == 0ull;
+            if (!valid) zeros = zeros && __builtin_amdgcn_ballot_w64(ob != 0u) == 0ull;
             return valid;
         };
         auto load16 = [&](F2 (&v)[16], int z) {

@@ -34,7 +34,16 @@
  * Depth grids: frames whose depths are all multiples of 1/256 m below 256 m -- what a KITTI depth PNG / 256 holds,
  * DC_lidar_only/main.cpp:75-82 -- let large device batches keep their intermediate image as 16-bit integers.  The library
  * finds that out itself on the device (and repeats the step with its f32 kernels when a frame turns out otherwise); results
- * are the same bits either way, and no promise about the values is asked of the caller.
+ * are the same bits either way, and no promise about the values is asked of the caller.  What it costs when the depths are NOT
+ * such multiples: a call that makes the attempt runs both of its large kernels twice (the 16-bit attempt, then the f32 kernels
+ * behind the flag the attempt raised), and the context then skips the attempt for its next 63 calls before trying once more --
+ * arbitrary f32 depths pay one double run in 64 calls.  Depths beyond 119.99 m (inverted values below -20 m: outside the 15-bit code
+ * range) count as "not on the grid" as well.
+ *
+ * In place: d_dst may be d_src (the reference's function is in place by signature: dense = sparse.clone(), :27), or overlap
+ * it; the library then never takes the 16-bit attempt (its f32 kernels read src completely before dst is first written).
+ * Empty pixels: the sign of a zero in an output pixel that stays empty (an all-empty frame) is +0.0 where the input held +0.0; an
+ * input -0.0 counts as 0.0 (empty) and may come out as either zero.
  */
 #ifndef DCMT_H
 #define DCMT_H
@@ -46,7 +55,7 @@
 extern "C" {
 #endif
 
-#define DCMT_VERSION 110 /* 0.1.1: dcmt_params grew norm_lo / norm_hi (DCMT_FLAG_NORMALIZE) */
+#define DCMT_VERSION 120 /* 0.1.2: dcmt_last_path; verbose == 2 (hole counts only: interpolate_with_superpixels) */
 
 typedef struct dcmt_ctx dcmt_ctx;
 
@@ -98,7 +107,9 @@ typedef struct {
                                 frames that have no holes left).  Default 1.  If a frame still has holes
                                 after them, dcmt_last_fill_iters() reports DCMT_E_NOT_CONVERGED for it. */
     int32_t stop_after;      /* dcmt_stage; DCMT_STAGE_FINAL for the whole chain */
-    int32_t verbose;         /* 1: print what the reference prints (dims, hole counts) to stdout (host entry points) */
+    int32_t verbose;         /* host entry points: 1 = print what img_completion prints to stdout (dimensions :29, "max range is" :50, one
+                                hole count per loop iteration :161); 2 = the hole counts only (all that interpolate_with_superpixels
+                                prints, img_completion_lc.cpp:173); 0 = nothing */
     int32_t flags;           /* DCMT_FLAG_* */
     float   norm_lo;         /* DCMT_FLAG_NORMALIZE: the two range arguments of cv::normalize (alpha, beta); */
     float   norm_hi;         /* the stereo-lidar callers pass (0, 100) and (0, 80).  Defaults 0, 100. */
@@ -127,9 +138,11 @@ typedef struct {
 int dcmt_device_count(void);
 
 /* Creates a context on `device` able to process up to max_batch frames of up to
- * max_rows x max_cols per call.  Allocates all device scratch up front (about
- * 14 B per pixel per frame of max_batch) so the call path never allocates.  A frame may hold at most 2^29 - 1
- * pixels (it is addressed with 32-bit byte offsets); max_batch at most 65535. */
+ * max_rows x max_cols per call.  Allocates the device scratch every path needs up front (12 B per
+ * pixel per frame of max_batch); two buffers only one path uses are allocated by the first call that takes it and kept (the
+ * 16-bit plane of large on-grid batches, 2 B per pixel; the column statistics of the small-batch tile kernels), so no call
+ * after the first of its kind allocates.  A frame may hold at most 2^29 - 16 pixels (it is addressed with 32-bit byte offsets
+ * and one offset just below 2^31 is kept free as "nowhere"); max_batch at most 65535. */
 int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx **out);
 void dcmt_destroy(dcmt_ctx *ctx);
 
@@ -275,6 +288,9 @@ int dcmt_last_holes_after_extend(dcmt_ctx *ctx, int *out, int n);
 
 const char *dcmt_strerror(int status);
 int dcmt_last_hip_error(const dcmt_ctx *ctx);
+/* The kernels the last cascade call on ctx dispatched, e.g. "k_pre_p<Q16OUT> + k_fp_q" (the dispatch depends on batch size,
+ * frame shape, alignment and -- for the 16-bit form -- on what earlier calls found in their frames).  Owned by ctx. */
+const char *dcmt_last_path(const dcmt_ctx *ctx);
 
 /* Measurement aid (bench.py's live per-kernel split).  With timing on, the streaming path of every following *_dev call
  * records HIP events on the caller's stream around its kernel groups (a few microseconds per call; off by default).

@@ -52,6 +52,10 @@ struct ThreadCtx {
     static int& device() { static int d = 0; return d; }     // dcmt_shim::ThreadCtx::device() = k selects the GPU
 };
 
+// The reference prints while it works (img_completion.cpp:29 the dimensions, :50 "max range is", :161 one hole count per loop
+// iteration; img_completion_lc.cpp:173 the hole counts only) and so does the drop-in; dcmt_shim::quiet() = true silences it.
+inline bool& quiet() { static bool q = false; return q; }
+
 inline ThreadCtx& thread_ctx()
 {
     static thread_local ThreadCtx t;
@@ -101,6 +105,7 @@ inline void interpolate_with_labels(const std::vector<std::vector<int> >& cluste
     dcmt_params p;
     dcmt_default_params(&p);
     if (normalize_range) { p.flags |= DCMT_FLAG_NORMALIZE; p.norm_lo = (float)normalize_range[0]; p.norm_hi = (float)normalize_range[1]; }
+    p.verbose = quiet() ? 0 : 2;                             // img_completion_lc.cpp:173
     const int st = dcmt_complete_labeled_f32(thread_ctx().get(rows, cols), sparse_r_img.ptr<float>(), sparse_r_img.step[0], 0,
                                              lab.data(), sizeof(int32_t) * (size_t)cols, 0, n_labels, out.ptr<float>(),
                                              out.step[0], 0, rows, cols, 1, &p, use_superpixel);
@@ -117,7 +122,6 @@ inline void img_completion_normalized(const cv::Mat& projected, cv::Mat& dense_r
 {
     check_input(projected);
     const int rows = projected.rows, cols = projected.cols;
-    std::cout << "NUMERO ROWS, COLS: " << rows << " " << cols << std::endl;   // img_completion.cpp:29
     cv::Mat out;
     out.create(rows, cols, CV_32FC1);
     dcmt_params p;
@@ -126,6 +130,8 @@ inline void img_completion_normalized(const cv::Mat& projected, cv::Mat& dense_r
     p.flags |= DCMT_FLAG_NORMALIZE;
     p.norm_lo = (float)alpha;
     p.norm_hi = (float)beta;
+    p.verbose = quiet() ? 0 : 2;                             // (the reference's "max range is" would be that of the normalised image: beta)
+    if (!quiet()) std::cout << "NUMERO ROWS, COLS: " << rows << " " << cols << std::endl << "max range is" << (float)(alpha > beta ? alpha : beta) << std::endl;
     const int st = dcmt_complete_f32(thread_ctx().get(rows, cols), projected.ptr<float>(), projected.step[0], 0,
                                      out.ptr<float>(), out.step[0], 0, rows, cols, 1, &p);
     raise(st, "img_completion_normalized");
@@ -186,12 +192,12 @@ inline void img_completion(const cv::Mat& sparse_r_img, cv::Mat& dense_r_img, co
 {
     dcmt_shim::check_input(sparse_r_img);
     const int rows = sparse_r_img.rows, cols = sparse_r_img.cols;
-    std::cout << "NUMERO ROWS, COLS: " << rows << " " << cols << std::endl;   // :29
     cv::Mat out;                              // the reference overwrites dense_r_img with a fresh clone (:27)
     out.create(rows, cols, CV_32FC1);
     dcmt_params p;
     dcmt_default_params(&p);
     p.blur = dcmt_shim::blur_from_string(blur_type);
+    p.verbose = dcmt_shim::quiet() ? 0 : 1;   // :29, :50, :161 -- printed by the library (stdout)
     const int st = dcmt_complete_f32(dcmt_shim::thread_ctx().get(rows, cols), sparse_r_img.ptr<float>(), sparse_r_img.step[0], 0,
                                      out.ptr<float>(), out.step[0], 0, rows, cols, 1, &p);
     dcmt_shim::raise(st, "img_completion");

@@ -53,7 +53,7 @@ def test_params_struct_layout_matches_header():
 
 
 def test_status_strings_and_version():
-    assert L.lib().dcmt_version() == 110
+    assert L.lib().dcmt_version() == 120
     for s in range(0, -7, -1):
         assert L.strerror(s) and L.strerror(s) != "unknown status"
     assert L.strerror(-99) == "unknown status"

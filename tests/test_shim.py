@@ -39,7 +39,14 @@ def test_cpp_caller_matches_oracle(tmp_path):
                         str(tmp_path / "lab.u8"), str(tmp_path / "out_slic.i32"), str(tmp_path / "right.u8"), str(tmp_path / "out_stereo.f32")],
                        capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    assert "NUMERO ROWS, COLS: 352 1216" in r.stdout          # the reference prints this (img_completion.cpp:29)
+    # what the reference prints (img_completion.cpp:29, :50, :161; img_completion_lc.cpp:173): the dimensions, the largest input value
+    # (operator<<(float): six significant digits), one hole count per loop iteration -- this frame's loop runs once and counts 0
+    want_info = O.img_completion(x, return_info=True)[1]
+    assert want_info["fill_iters"] == 1
+    lines = r.stdout.splitlines()
+    k = lines.index("NUMERO ROWS, COLS: 352 1216")
+    assert lines[k + 1] == "max range is%g" % float(x.max()) and lines[k + 2] == "0", lines[k:k + 4]
+    assert lines[k + 3] == "0", lines[k:k + 5]               # interpolate_with_superpixels: the hole count only
     got = np.fromfile(tmp_path / "out.f32", dtype=np.float32).reshape(rows, cols)
     assert_bit_equal(got, O.img_completion(x), "C++ img_completion")
     got_lc = np.fromfile(tmp_path / "out_lc.f32", dtype=np.float32).reshape(rows, cols)
