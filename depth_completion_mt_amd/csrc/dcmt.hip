@@ -21,6 +21,7 @@
 #include "dcmt_kernels_pair.h"
 #include "dcmt_kernels_fp_pair.h"
 #include "dcmt_kernels_fp_q16.h"
+#include "dcmt_kernels_fp_h16.h"
 #include "dcmt_kernels_slic.h"
 
 using namespace dcmt;
@@ -65,6 +66,8 @@ struct dcmt_ctx {
     int fp_q16 = 1;                   // X6 as 16-bit codes + k_fp_q wherever the frames allow it (multiples of 1/256 m: checked on the device, the f32
                                       // kernels rerun behind a raised flag); env DCMT_FP_Q16=0 disables
     int assume_filled = 1;            // k_fp_s / k_fp_q without the median >= thr select where the redo chain follows; env DCMT_ASSUME_FILLED=0 keeps it
+    int fp_h = 0;                     // env DCMT_FP_H=1: k_fp_h (the horizontal 31-maximum as a row pipeline through LDS: fewer VALU instructions, measured slower) instead of
+                                      // k_fp_q
     int q16_breg = 1;                 // k_fp_q with the halo columns in a second register (120 output columns per wave, 3 waves per SIMD); 0 = wider strip
                                       // overlap instead (88 output columns, 4 waves per SIMD: measured 2.5 % slower -- the kernel is bound by issue, not by
                                       // occupancy); env DCMT_Q16_BREG
@@ -257,10 +260,10 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
     const bool bl = p->blur == DCMT_BLUR_GAUSSIAN;
     int rc = DCMT_OK, apps_all = 0;
     // 16-bit X6: a frame that is no multiple of 1/256 m costs the attempt AND the f32 rerun; once a call has raised the flag (seen
-    // here at the start of a later call, without synchronising) the next 63 calls go straight to the f32 kernels.  Depths the uint16
-    // entry point converts itself are codes by construction and always take the 16-bit form.
+    // here at the start of a later call, without synchronising) the next 63 calls go straight to the f32 kernels.  (The uint16 entry
+    // point's depths are multiples of 1/256 m by construction, but a payload beyond 30719 -- 119.996 m -- has no code either.)
     bool q16_try = ctx->fp_q16 != 0;
-    if (q16_try && !d_src16) {
+    if (q16_try) {
         if (*(volatile int*)ctx->q16_seen) { *(volatile int*)ctx->q16_seen = 0; ctx->q16_skip = 63; }
         if (ctx->q16_skip > 0) { --ctx->q16_skip; q16_try = false; }
     }
@@ -352,19 +355,27 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             // frames this kernel leaves with holes are recomputed by the redo chain below whenever that chain is enqueued (always on the host
             // entry points, with spec_fill_iters >= 1 on the device ones): then the kernel may leave out the select that only such frames need
             const bool filled = bl && ctx->assume_filled && (sync_loop || (p->spec_fill_iters >= 1 && p->max_fill_iters >= 1));
-            const bool src16_q = d_src16 != nullptr;          // codes by construction: no rerun needed
             if (q16) {
                 const void* xq = ctx->x6q + f0 * fe;
 #define DCMT_FPQ(BL, BREG, FILLED) { const int qstrips = (cols + FpQ::vw<BREG>() - 1) / FpQ::vw<BREG>(); \
                     hipLaunchKernelGGL((k_fp_q<BL, true, BREG, FILLED>), wave_grid(qstrips, nb, xm), b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, \
                                        p->max_depth, p->valid_thresh, (const int*)tc, bands); }
-                if (ctx->q16_breg) { if (filled) DCMT_FPQ(true, true, true) else if (bl) DCMT_FPQ(true, true, false) else DCMT_FPQ(false, true, false) }
+#define DCMT_FPH(BL, FILLED) { const int qstrips = (cols + FpP::VW - 1) / FpP::VW; \
+                    hipLaunchKernelGGL((k_fp_h<BL, FILLED>), wave_grid(qstrips, nb, xm), b256, 0, st, xq, dst, cnt, rows, cols, qstrips, nb, xm, \
+                                       p->max_depth, p->valid_thresh, (const int*)tc, bands); }
+                // (k_fp_h<BLUR, !FILLED> -- the select of LO :184 kept, only where a device caller asks for no speculative loop applications -- needs more
+                //  than the 168 registers three waves per SIMD leave: that combination stays with k_fp_q)
+                const bool fph = ctx->fp_h && ctx->q16_breg && (filled || !bl);
+                if (fph) { if (filled) DCMT_FPH(true, true) else DCMT_FPH(false, false) }
+                else if (ctx->q16_breg) { if (filled) DCMT_FPQ(true, true, true) else if (bl) DCMT_FPQ(true, true, false) else DCMT_FPQ(false, true, false) }
                 else               { if (bl) DCMT_FPQ(true, false, false) else DCMT_FPQ(false, false, false) }
 #undef DCMT_FPQ
-                if (!src16_q) {
+#undef DCMT_FPH
+                {
                     // frames that are no multiples of 1/256 m: both f32 kernels again, gated on the flag the attempt raised (they return at once otherwise)
+                    // (the uint16 entry point too: a payload beyond 30719 = 119.996 m has no code)
                     float* o6 = x6;
-                    const uint16_t* src16 = nullptr; const float* cf = nullptr; const hipStream_t ps = st;
+                    const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr; const float* cf = nullptr; const hipStream_t ps = st;
                     const float* src = (d_x4 ? d_x4 : d_src) + f0 * fe;
                     if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)ctx->q16_bad) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)ctx->q16_bad)
                     if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
@@ -385,7 +396,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             DCMT_HIP(ctx, hipGetLastError());
             stamp(3);
             { const size_t n_ = std::strlen(ctx->last_path);
-              std::snprintf(ctx->last_path + n_, sizeof ctx->last_path - n_, " + %s", q16 ? "k_fp_q" : fpp ? "k_fp_p" : "k_fp_s"); }
+              std::snprintf(ctx->last_path + n_, sizeof ctx->last_path - n_, " + %s", q16 ? (ctx->fp_h && ctx->q16_breg && (filled || !bl) ? "k_fp_h" : "k_fp_q") : fpp ? "k_fp_p" : "k_fp_s"); }
             ctx->last_has_loop = 1;
             const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);
             if (n_redo > 0) {
@@ -769,6 +780,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_FP_Q16"); if (e) ctx->fp_q16 = std::atoi(e); }
     { const char* e = std::getenv("DCMT_Q16_MIN_WAVES"); if (e) ctx->q16_min_waves = std::atoi(e); }
     { const char* e = std::getenv("DCMT_Q16_BREG"); if (e) ctx->q16_breg = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_FP_H"); if (e) ctx->fp_h = std::atoi(e); }
     { const char* e = std::getenv("DCMT_ASSUME_FILLED"); if (e) ctx->assume_filled = std::atoi(e); }
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }

@@ -39,6 +39,28 @@ __device__ __forceinline__ unsigned qmin(unsigned a, unsigned b)
 }
 __device__ __forceinline__ unsigned umax2(unsigned a, unsigned b) { return a > b ? a : b; }
 
+// The codes are ordered as f16 too (Q16, dcmt_kernels_fused.h), and for f16 -- for nothing else 16 bits wide -- gfx950 has packed THREE-input
+// minima / maxima: v_pk_maximum3_f16 / v_pk_minimum3_f16 (tools/pk3_probe.hip: exact on these bit patterns, the price of one v_pk_max_u16).
+typedef _Float16 hf2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned hmax2(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_maximum(__builtin_bit_cast(hf2v, a), __builtin_bit_cast(hf2v, b)));
+}
+__device__ __forceinline__ unsigned hmin2(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_minimum(__builtin_bit_cast(hf2v, a), __builtin_bit_cast(hf2v, b)));
+}
+__device__ __forceinline__ unsigned hmax3(unsigned a, unsigned b, unsigned c)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(hf2v, a), __builtin_bit_cast(hf2v, b)), __builtin_bit_cast(hf2v, c)));
+}
+__device__ __forceinline__ unsigned hmin3(unsigned a, unsigned b, unsigned c)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(hf2v, a), __builtin_bit_cast(hf2v, b)), __builtin_bit_cast(hf2v, c)));
+}
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return umax2(umax2(a, b), c); }
+
+
 
 // shifts with 0 in the lane without a source (unsigned codes: 0 is the neutral element of max)
 __device__ __forceinline__ unsigned u_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); }
@@ -98,13 +120,12 @@ __device__ __forceinline__ void q_mid20(const unsigned (&pa)[10], const unsigned
 #undef DCMT_QCX
 #undef DCMT_QCMIN
 #undef DCMT_QCMAX
-// 6th smallest of sorted C (6) u sorted a (5): min(C5, max(a0,C4), max(a1,C3), max(a2,C2), max(a3,C1), max(a4,C0))
+// 6th smallest of sorted C (6) u sorted a (5): min(C5, max(a0,C4), max(a1,C3), max(a2,C2), max(a3,C1), max(a4,C0)); the six-way minimum
+// in three-input instructions: 5 + 3 instead of 5 + 5
 __device__ __forceinline__ unsigned q_final6(const unsigned (&C)[6], const unsigned (&a)[5])
 {
-    unsigned r = C[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r = qmin(r, qmax(a[i], C[4 - i]));
-    return r;
+    const unsigned m0 = hmax2(a[0], C[4]), m1 = hmax2(a[1], C[3]), m2 = hmax2(a[2], C[2]), m3 = hmax2(a[3], C[1]), m4 = hmax2(a[4], C[0]);
+    return hmin2(hmin3(C[5], m0, m1), hmin3(m2, m3, m4));
 }
 struct MedianColumnQ {       // MedianColumn (dcmt_median.h) on packed pairs
     unsigned SE[4][5], SO[5], P[2][10], C[6];
@@ -277,18 +298,18 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
         if (o >= rows) { asm volatile("" ::); x7 = x7_prev; }
         x7_prev = x7;
         // vertical 31-max: A packed (two-input instructions), B unpacked
-        const unsigned w2a = qmax(xa, vpa);
+        const unsigned w2a = hmax2(xa, vpa);
         vpa = xa;
         W2A[p] = w2a;
-        const unsigned w6a = qmax(qmax(w2a, W2A[(p + 14) & 15]), W2A[(p + 12) & 15]);
+        const unsigned w6a = hmax3(w2a, W2A[(p + 14) & 15], W2A[(p + 12) & 15]);
         W6A[p] = w6a;
-        const unsigned w18a = qmax(qmax(w6a, W6A[(p + 10) & 15]), W6A[(p + 4) & 15]);
+        const unsigned w18a = hmax3(w6a, W6A[(p + 10) & 15], W6A[(p + 4) & 15]);
         const unsigned v = nxt_c, w18a_old = nxt_a;
         nxt_c = dl_c[(p + 2) & 15][lane];
         nxt_a = dl_a[(p + 4) & 15][lane];
         dl_c[p][lane] = xa;
         dl_a[p][lane] = w18a;
-        const unsigned w31a = qmax(w18a, w18a_old);
+        const unsigned w31a = hmax2(w18a, w18a_old);
         unsigned w31b = 0;
         if constexpr (BREG) {
             const unsigned w2b = umax2(xb, vpb);

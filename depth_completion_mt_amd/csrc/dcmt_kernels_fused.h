@@ -80,13 +80,19 @@ struct FrameBuf {
 };
 
 
-// 16-bit codes of depths that are multiples of 1/256 m (k_pre_p<Q16OUT> -> k_fp_q, dcmt_kernels_fp_q16.h has the argument)
+// 16-bit codes of depths that are multiples of 1/256 m (k_pre_p<Q16OUT> -> k_fp_h / k_fp_q, dcmt_kernels_fp_q16.h has the argument).
+// code = 256 x + 6143 for x = j / 256, j in [-5119, 25600] (an empty pixel, an inverted depth down to 100 - 119.996 m, the 100 of an
+// empty column): 0x0400 .. 0x7bff -- the bit patterns of the positive NORMAL half-floats, which order exactly like the integers they
+// are.  So the codes can be compared as unsigned integers (v_pk_max_u16 ...) AND as f16 (v_pk_maximum3_f16 / v_pk_minimum3_f16:
+// gfx950's only packed three-input min / max; tools/pk3_probe.hip checks the ordering on the device, subnormals included).
+// A depth beyond 119.996 m has no code: the check in k_pre_p raises the flag and the f32 kernels rerun.
 struct Q16 {
-    static constexpr int OFFSET = 39935;                         // code = 256 x + OFFSET: x = j / 256, j in [-39935, 25600]
+    static constexpr int OFFSET = 6143;
+    static constexpr unsigned CODE_MIN = 0x0400u, CODE_MAX = 0x7bffu;    // = 25600 + OFFSET: the 100 of LO :110
     static constexpr unsigned HOLE_MAX = 25 + OFFSET;            // x < 0.1f  <=>  256 x <= 25  <=>  code <= HOLE_MAX
     static constexpr unsigned HOLE_MAX_HI = (HOLE_MAX << 16) | 0xffffu;   // the same test on the high half of a packed pair
     __device__ static __forceinline__ unsigned code(float x) { return (unsigned)((int)__fmul_rn(x, 256.0f) + OFFSET); }
-    __device__ static __forceinline__ float value(unsigned c) { return __builtin_fmaf((float)c, 0.00390625f, -155.99609375f); }   // (c - 39935) / 256, exact
+    __device__ static __forceinline__ float value(unsigned c) { return __builtin_fmaf((float)c, 0.00390625f, -23.99609375f); }   // (c - 6143) / 256, exact
     __host__ __device__ static bool params_ok(float max_depth, float thr) { return max_depth == 100.0f && thr == 0.1f; }
 };
 

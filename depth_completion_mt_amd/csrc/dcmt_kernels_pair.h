@@ -75,7 +75,7 @@ constexpr int kMaxBands = 8;                 // row bands per strip (table slots
 // with cold rings (exactly like the start below the leading empty rows) and accounts for the x5 rows [r0, r1) only; the
 // per-column (ti, bi) of the bands go to one table slot per band, which the reader combines (table_rows), which is why
 // bands need table mode.
-// Q16OUT: X6 leaves as 16-bit codes (Q16 below: code = 256 x + 39935, two columns per dword) for k_fp_q -- half the X6 traffic.
+// Q16OUT: X6 leaves as 16-bit codes (Q16 in dcmt_kernels_fused.h: code = 256 x + 6143, two columns per dword) for k_fp_h / k_fp_q -- half the X6 traffic.
 // Exact only if every value stored is a multiple of 1/256 in the code range, which holds whenever the frame's depths are
 // (the KITTI format); the kernel checks it on every value it really stores and raises *q16_bad otherwise (the caller then
 // reruns the f32 kernels, gated on that flag).  Table mode only.
@@ -271,15 +271,16 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             // first one here are real holes that the reader looks at)
             const bool real = inrows && outlane && (band > 0 || m >= min(tie, tio));
             if constexpr (Q16OUT) {
-                // code = 256 x + 39935 through the float adder: y = fma(x, 256, 39935 + 2^23) lies in [2^23, 2^24) for every code, where the
+                // code = 256 x + OFFSET through the float adder: y = fma(x, 256, OFFSET + 2^23) lies in [2^23, 2^24) for every code, where the
                 // low mantissa bits ARE the integer -- no v_cvt (adds and logic ops issue beside the chain's max / min instructions).
-                // Exact iff 256 x is an integer in range: then y - (39935 + 2^23) gives 256 x back bit for bit; anything else (a fraction,
-                // -0.0, a value out of range, NaN, Inf) leaves a difference or a code above 16 bits.
-                constexpr float kMagic = 8428543.0f;                     // 39935 + 8388608
+                // Exact iff 256 x is an integer: then y - (OFFSET + 2^23) gives 256 x back bit for bit; anything else (a fraction, -0.0, NaN,
+                // Inf) leaves a difference.  The range: u - CODE_MIN and CODE_MAX - u both wrap to something huge outside [CODE_MIN, CODE_MAX].
+                constexpr float kMagic = (float)(Q16::OFFSET + 8388608);
                 const float ye = __builtin_fmaf(x5.e, 256.0f, kMagic), yo = __builtin_fmaf(x5.o, 256.0f, kMagic);
                 const unsigned ue = __builtin_bit_cast(unsigned, ye) - 0x4B000000u, uo = __builtin_bit_cast(unsigned, yo) - 0x4B000000u;
                 const unsigned diff = (__builtin_bit_cast(unsigned, __fsub_rn(ye, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.e, 256.0f))) |
-                                      (__builtin_bit_cast(unsigned, __fsub_rn(yo, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.o, 256.0f))) | ((ue | uo) >> 16);
+                                      (__builtin_bit_cast(unsigned, __fsub_rn(yo, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.o, 256.0f))) |
+                                      (((ue - Q16::CODE_MIN) | (uo - Q16::CODE_MIN) | (Q16::CODE_MAX - ue) | (Q16::CODE_MAX - uo)) >> 15);
                 bad |= real ? diff : 0u;
                 __builtin_amdgcn_raw_buffer_store_b32(ue | (uo << 16), ob.rs, real ? qc : kDropOffset, (inrows ? m : 0) * cols * 2, 0);
             } else {
@@ -297,9 +298,9 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
             const bool ee = bie < 0, eo = bio < 0;
             if ((ee | eo) && band == bands - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if constexpr (Q16OUT) {                                   // 100 = code 65535
-                    if (ee) __builtin_amdgcn_raw_buffer_store_b16((short)0xffff, ob.rs, qc + 2u * (unsigned)((rows - 1) * cols), 0, 0);
-                    if (eo) __builtin_amdgcn_raw_buffer_store_b16((short)0xffff, ob.rs, qc + 2u + 2u * (unsigned)((rows - 1) * cols), 0, 0);
+                if constexpr (Q16OUT) {                                   // 100 = the largest code
+                    if (ee) __builtin_amdgcn_raw_buffer_store_b16((short)Q16::CODE_MAX, ob.rs, qc + 2u * (unsigned)((rows - 1) * cols), 0, 0);
+                    if (eo) __builtin_amdgcn_raw_buffer_store_b16((short)Q16::CODE_MAX, ob.rs, qc + 2u + 2u * (unsigned)((rows - 1) * cols), 0, 0);
                 } else {
                     if (ee) ob.st_at(oc + 4u * (unsigned)((rows - 1) * cols), 100.0f);
                     if (eo) ob.st_at(oc + 4u + 4u * (unsigned)((rows - 1) * cols), 100.0f);
