@@ -71,9 +71,9 @@ struct dcmt_ctx {
     int q16_breg = 1;                 // k_fp_q with the halo columns in a second register (120 output columns per wave, 3 waves per SIMD); 0 = wider strip
                                       // overlap instead (88 output columns, 4 waves per SIMD: measured 2.5 % slower -- the kernel is bound by issue, not by
                                       // occupancy); env DCMT_Q16_BREG
-    int q16_min_waves = 6600;         // ... and the batch is large enough: k_fp_q has half as many, longer waves than k_fp_s (3 per SIMD instead of 4), so it
-                                      // only pays from ~2 rounds of them on (measured, 352x1216, frames per call: 128 -14 %, 384 -3 %, 512 +-0, 640 +3 %,
-                                      // 896 +4 %, 1024 +5 %); env DCMT_Q16_MIN_WAVES
+    int q16_min_waves = 2600;         // ... and the batch is large enough: k_fp_q has half as many, longer waves than k_fp_s (3 per SIMD instead of 4), so it
+                                      // only pays from about one round of them on (measured, 352x1216, frames per call, whole step against the f32 kernels:
+                                      // 128 -12 %, 256 +3 %, 512 +4 %, 1024 +5 %; threshold = 236 frames); env DCMT_Q16_MIN_WAVES
     unsigned short* x6q = nullptr;    // [max_batch][rows][cols] X6 as 16-bit codes (k_pre_p<Q16OUT> -> k_fp_q)
     int* q16_bad = nullptr;           // raised by k_pre_p<Q16OUT> when a value it stored was not a code
     int* q16_seen = nullptr;          // pinned host word (and its device address) the same kernel sets: the NEXT calls skip the 16-bit attempt

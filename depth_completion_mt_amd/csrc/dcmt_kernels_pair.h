@@ -203,91 +203,128 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     for (int q = 0; q < PFD; ++q) PF[q] = load_row(min(max(S + q - ROFF, 0), rows - 1));
 
     int tie = 0x7fffffff, tio = 0x7fffffff, bie = -1, bio = -1;   // first / last valid row of X5 in this lane's two columns (within the band)
+    unsigned long long seen_e = 0, seen_o = 0;                   // columns that have had their first valid row (wave masks)
+    // Q16OUT, raw f32 input: the grid check is made on every INPUT value the stream consumes (below); the running maxima of the codes
+    // and the OR of the residues are looked at once, behind the loop
+    unsigned chk_max = 0, chk_or = 0;
 
     const int nsteps = r1 + G::LAT;
-    for (int i0 = S; i0 < nsteps; i0 += 8) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int i = i0 + p;
-            F2 raw = PF[p];
-            PF[(p + PFD) & 7] = load_row(min(max(i + PFD - ROFF, 0), rows - 1));
-            F2 e4;
-            const int l = i - 6;
-            if constexpr (START4) {
-                e4 = raw;                                               // X4 row l
+    // One row step.  INNER: every row the step touches (i - 6 .. i) lies inside the image, every lane's columns do, and the x5 row
+    // it finishes belongs to this wave -- the border selects (one per stage and column) and the row tests are compiled out.  The
+    // host of the loop below decides per block of eight steps; strips at the image's left / right edge never qualify.
+    auto row_step = [&](auto INNER_, auto P_, int i) __attribute__((always_inline)) {
+        constexpr bool INNER = decltype(INNER_)::value;
+        constexpr int p = decltype(P_)::value;
+        F2 raw = PF[p];
+        PF[(p + PFD) & 7] = load_row(INNER ? i + PFD - ROFF : min(max(i + PFD - ROFF, 0), rows - 1));
+        F2 e4;
+        const int l = i - 6;
+        if constexpr (START4) {
+            e4 = raw;                                               // X4 row l
+        } else {
+            if constexpr (NORM) raw = {norm_apply(raw.e, na, nb), norm_apply(raw.o, na, nb)};
+            if constexpr (Q16OUT && !U16) {
+                // is every depth a multiple of 1/256 m with a code (Q16: 256 x in [-5119, 30719])?  t = fma(x, 256, 1.5 * 2^23) lies in
+                // [2^23, 2^24) for every such x, where the float IS the integer 256 x + 1.5 * 2^23 (low mantissa bits): its distance from
+                // the smallest admissible value, as an unsigned number, is at most 35838 -- anything out of range wraps to more --, and
+                // 256 x - (t - 1.5 * 2^23), one fused operation, is zero iff nothing was rounded away.  Adds, not compares: these issue
+                // beside the chain's max / min instructions.  Every value loaded is a pixel of the frame (clamped rows and columns repeat
+                // pixels), so no lane needs masking; the values the kernel stores are selections of the inputs and of 100 - input.
+                constexpr float kMg = 12582912.0f;                   // 1.5 * 2^23
+                constexpr unsigned kBase = 0x4B000000u + 4194304u - 5119u;
+                const float te = __builtin_fmaf(raw.e, 256.0f, kMg), to = __builtin_fmaf(raw.o, 256.0f, kMg);
+                const float re = __builtin_fmaf(raw.e, 256.0f, -__fsub_rn(te, kMg)), ro = __builtin_fmaf(raw.o, 256.0f, -__fsub_rn(to, kMg));
+                chk_max = max(max(chk_max, __builtin_bit_cast(unsigned, te) - kBase), __builtin_bit_cast(unsigned, to) - kBase);
+                chk_or |= __builtin_bit_cast(unsigned, re) | __builtin_bit_cast(unsigned, ro);
+            }
+            // ---- H2 on load (LO :55-67); outside the image: the dilate border value
+            F2 x2 = {invert_valid(raw.e, max_depth, thr), invert_valid(raw.o, max_depth, thr)};
+            if constexpr (!INNER) x2 = p_sel(incol && i < rows, x2, NEG2);
+            // ---- H3 (LO :71-80), row j = i - 2
+            const int j = i - 2;
+            F2 y3;
+            if constexpr (K0KIND == K0_AS_COMPILED) {
+                // dst(r,c) = max(src(r-1,c+1), src(r+2,c+2)).  c = 2l: O[l] of row j-1, E[l+1] of row j+2; c = 2l+1: E[l+1] of row j-1, O[l+1] of row j+2
+                const float s1e = from_right(x2.e);
+                y3.e = fmax2(OX[(p + 5) & 7], s1e);
+                y3.o = fmax2(from_right(x2.o), S1E[(p + 5) & 7]);
+                OX[p] = x2.o;
+                S1E[p] = s1e;
             } else {
-                if constexpr (NORM) raw = {norm_apply(raw.e, na, nb), norm_apply(raw.o, na, nb)};
-                // ---- H2 on load (LO :55-67); outside the image: the dilate border value
-                const bool in2 = incol && i < rows;
-                const F2 x2 = {in2 ? invert_valid(raw.e, max_depth, thr) : NEG, in2 ? invert_valid(raw.o, max_depth, thr) : NEG};
-                // ---- H3 (LO :71-80), row j = i - 2
-                const int j = i - 2;
-                F2 y3;
-                if constexpr (K0KIND == K0_AS_COMPILED) {
-                    // dst(r,c) = max(src(r-1,c+1), src(r+2,c+2)).  c = 2l: O[l] of row j-1, E[l+1] of row j+2; c = 2l+1: E[l+1] of row j-1, O[l+1] of row j+2
-                    const float s1e = from_right(x2.e);
-                    y3.e = fmax2(OX[(p + 5) & 7], s1e);
-                    y3.o = fmax2(from_right(x2.o), S1E[(p + 5) & 7]);
-                    OX[p] = x2.o;
-                    S1E[p] = s1e;
-                } else {
-                    // 13-tap diamond: rows j-2 and j+2 centre only, j-1 and j+1 three wide, j five wide
-                    const F2 a3 = p_hmax3(x2);
-                    XR[p] = x2;
-                    A3[p] = a3;
-                    const F2 a5j = p_grow_max(A3[(p + 6) & 7]);          // row j
-                    y3 = p_max(p_max3(XR[(p + 4) & 7] /* j-2 */, A3[(p + 5) & 7] /* j-1 */, a5j), p_max(A3[(p + 7) & 7] /* j+1 */, x2 /* j+2 */));
-                }
-                y3 = p_sel(incol && (unsigned)j < (unsigned)rows, y3, NEG2);
-                // ---- H4 dilate 5x5 (LO :85): horizontal on row j, vertical gives row k = j - 2
-                H4[(p + 6) & 7] = p_grow_max(p_hmax3(y3));
-                const int k = i - 4;
-                F2 d4 = p_max3(p_max3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
-                d4 = p_sel(incol && (unsigned)k < (unsigned)rows, d4, POS2);     // border value of the erode
-                // ---- H4 erode 5x5: row l = k - 2
-                HE[(p + 4) & 7] = p_grow_min(p_hmin3(d4));
-                e4 = p_min3(p_min3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+                // 13-tap diamond: rows j-2 and j+2 centre only, j-1 and j+1 three wide, j five wide
+                const F2 a3 = p_hmax3(x2);
+                XR[p] = x2;
+                A3[p] = a3;
+                const F2 a5j = p_grow_max(A3[(p + 6) & 7]);          // row j
+                y3 = p_max(p_max3(XR[(p + 4) & 7] /* j-2 */, A3[(p + 5) & 7] /* j-1 */, a5j), p_max(A3[(p + 7) & 7] /* j+1 */, x2 /* j+2 */));
             }
-            e4 = p_sel(incol && (unsigned)l < (unsigned)rows, e4, NEG2);         // border value of the 7x7 dilate
-            E4[(p + 2) & 7] = e4;                                                // slot of row l = i-6
-            // ---- H5 (LO :88-100): dilate 7x7, row m = l - 3, then fill where x < 0.1
-            H7[(p + 2) & 7] = p_grow_max(p_grow_max(p_hmax3(e4)));
-            const int m = i - 9;
-            T7[p] = p_max3(H7[(p + 0) & 7], H7[(p + 1) & 7], H7[(p + 2) & 7]);   // rows i-8 .. i-6
-            const F2 d7 = p_max3(T7[p], T7[(p + 5) & 7] /* rows i-11 .. i-9 */, H7[(p + 4) & 7] /* row i-12 */);
-            const F2 e = E4[(p + 7) & 7];                                        // row m = i-9
-            const F2 x5 = {e.e < thr ? d7.e : e.e, e.o < thr ? d7.o : e.o};
-            const bool inrows = m >= m0 && m < r1;
-            if (inrows) {
-                // ---- H6 bookkeeping (LO :112-121): first / last row with x >= 0.1
-                const bool ve = x5.e >= thr, vo = x5.o >= thr;
-                tie = min(tie, ve ? m : 0x7fffffff); tio = min(tio, vo ? m : 0x7fffffff);
-                bie = ve ? m : bie; bio = vo ? m : bio;
-            }
-            // both columns leave in one 8-byte store once either has had its first valid row (what lands above a column's own first
-            // valid row is never read in table mode and rewritten by the epilogue otherwise); the store itself is issued on every
-            // step by every lane, aimed past the buffer when there is nothing to write (no branch in the row step)
-            // (a band below the first one stores all its rows: the rows between a column's first valid row in an upper band and its
-            // first one here are real holes that the reader looks at)
-            const bool real = inrows && outlane && (band > 0 || m >= min(tie, tio));
-            if constexpr (Q16OUT) {
-                // code = 256 x + OFFSET through the float adder: y = fma(x, 256, OFFSET + 2^23) lies in [2^23, 2^24) for every code, where the
-                // low mantissa bits ARE the integer -- no v_cvt (adds and logic ops issue beside the chain's max / min instructions).
-                // Exact iff 256 x is an integer: then y - (OFFSET + 2^23) gives 256 x back bit for bit; anything else (a fraction, -0.0, NaN,
-                // Inf) leaves a difference.  The range: u - CODE_MIN and CODE_MAX - u both wrap to something huge outside [CODE_MIN, CODE_MAX].
-                constexpr float kMagic = (float)(Q16::OFFSET + 8388608);
-                const float ye = __builtin_fmaf(x5.e, 256.0f, kMagic), yo = __builtin_fmaf(x5.o, 256.0f, kMagic);
+            if constexpr (!INNER) y3 = p_sel(incol && (unsigned)j < (unsigned)rows, y3, NEG2);
+            // ---- H4 dilate 5x5 (LO :85): horizontal on row j, vertical gives row k = j - 2
+            H4[(p + 6) & 7] = p_grow_max(p_hmax3(y3));
+            const int k = i - 4;
+            F2 d4 = p_max3(p_max3(H4[(p + 2) & 7], H4[(p + 3) & 7], H4[(p + 4) & 7]), H4[(p + 5) & 7], H4[(p + 6) & 7]);
+            if constexpr (!INNER) d4 = p_sel(incol && (unsigned)k < (unsigned)rows, d4, POS2);     // border value of the erode
+            // ---- H4 erode 5x5: row l = k - 2
+            HE[(p + 4) & 7] = p_grow_min(p_hmin3(d4));
+            e4 = p_min3(p_min3(HE[(p + 0) & 7], HE[(p + 1) & 7], HE[(p + 2) & 7]), HE[(p + 3) & 7], HE[(p + 4) & 7]);
+        }
+        if constexpr (!INNER) e4 = p_sel(incol && (unsigned)l < (unsigned)rows, e4, NEG2);         // border value of the 7x7 dilate
+        E4[(p + 2) & 7] = e4;                                                // slot of row l = i-6
+        // ---- H5 (LO :88-100): dilate 7x7, row m = l - 3, then fill where x < 0.1
+        H7[(p + 2) & 7] = p_grow_max(p_grow_max(p_hmax3(e4)));
+        const int m = i - 9;
+        T7[p] = p_max3(H7[(p + 0) & 7], H7[(p + 1) & 7], H7[(p + 2) & 7]);   // rows i-8 .. i-6
+        const F2 d7 = p_max3(T7[p], T7[(p + 5) & 7] /* rows i-11 .. i-9 */, H7[(p + 4) & 7] /* row i-12 */);
+        const F2 e = E4[(p + 7) & 7];                                        // row m = i-9
+        const F2 x5 = {e.e < thr ? d7.e : e.e, e.o < thr ? d7.o : e.o};
+        const bool inrows = INNER || (m >= m0 && m < r1);
+        if (inrows) {
+            // ---- H6 bookkeeping (LO :112-121): first / last row with x >= 0.1.  The compare's wave mask is all that is needed: the last
+            // valid row is "this row, where valid", the first one "this row, where valid for the first time" -- one select each
+            const unsigned long long ve = __builtin_amdgcn_ballot_w64(x5.e >= thr), vo = __builtin_amdgcn_ballot_w64(x5.o >= thr);
+            tie = __builtin_amdgcn_inverse_ballot_w64(ve & ~seen_e) ? m : tie; tio = __builtin_amdgcn_inverse_ballot_w64(vo & ~seen_o) ? m : tio;
+            bie = __builtin_amdgcn_inverse_ballot_w64(ve) ? m : bie; bio = __builtin_amdgcn_inverse_ballot_w64(vo) ? m : bio;
+            seen_e |= ve; seen_o |= vo;
+        }
+        // both columns leave in one 8-byte store once either has had its first valid row (what lands above a column's own first
+        // valid row is never read in table mode and rewritten by the epilogue otherwise); the store itself is issued on every
+        // step by every lane, aimed past the buffer when there is nothing to write (no branch in the row step)
+        // (a band below the first one stores all its rows: the rows between a column's first valid row in an upper band and its
+        // first one here are real holes that the reader looks at)
+        const bool real = inrows && outlane && (band > 0 || __builtin_amdgcn_inverse_ballot_w64(seen_e | seen_o));
+        if constexpr (Q16OUT) {
+            // code = 256 x + OFFSET through the float adder: y = fma(x, 256, OFFSET + 2^23) lies in [2^23, 2^24) for every code, where the
+            // low mantissa bits ARE the integer -- no v_cvt; the two low halves leave as one dword (v_perm_b32)
+            constexpr float kMagic = (float)(Q16::OFFSET + 8388608);
+            const float ye = __builtin_fmaf(x5.e, 256.0f, kMagic), yo = __builtin_fmaf(x5.o, 256.0f, kMagic);
+            if constexpr (START4 || U16) {
+                // not fed by raw f32 frames (X4 of the label-masked stage; the uint16 payload, whose scale may be any): the values stored are
+                // checked themselves.  Exact iff 256 x is an integer: then y - (OFFSET + 2^23) gives 256 x back bit for bit; the range: u -
+                // CODE_MIN and CODE_MAX - u both wrap to something huge outside [CODE_MIN, CODE_MAX].
                 const unsigned ue = __builtin_bit_cast(unsigned, ye) - 0x4B000000u, uo = __builtin_bit_cast(unsigned, yo) - 0x4B000000u;
                 const unsigned diff = (__builtin_bit_cast(unsigned, __fsub_rn(ye, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.e, 256.0f))) |
                                       (__builtin_bit_cast(unsigned, __fsub_rn(yo, kMagic)) ^ __builtin_bit_cast(unsigned, __fmul_rn(x5.o, 256.0f))) |
                                       (((ue - Q16::CODE_MIN) | (uo - Q16::CODE_MIN) | (Q16::CODE_MAX - ue) | (Q16::CODE_MAX - uo)) >> 15);
                 bad |= real ? diff : 0u;
-                __builtin_amdgcn_raw_buffer_store_b32(ue | (uo << 16), ob.rs, real ? qc : kDropOffset, (inrows ? m : 0) * cols * 2, 0);
-            } else {
-                st2(ob, real ? oc : kDropOffset, inrows ? m : 0, cols, x5);
             }
+            const unsigned packed = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, yo), __builtin_bit_cast(unsigned, ye), 0x05040100u);
+            __builtin_amdgcn_raw_buffer_store_b32(packed, ob.rs, real ? qc : kDropOffset, (inrows ? m : 0) * cols * 2, 0);
+        } else {
+            st2(ob, real ? oc : kDropOffset, inrows ? m : 0, cols, x5);
         }
-    }
+    };
+    // three loops, not one loop with a choice inside (which costs 40 registers: the allocator then has to agree on every ring slot's
+    // register across two unrolled bodies): the blocks of eight steps in front of the first inner one, the inner ones, the rest
+    const bool strip_inner = gx0 >= 0 && gx0 + 127 < cols;
+    const int inner_lo = max(START4 ? 6 + ROFF : 6, m0 + 9), inner_hi = min(rows + ROFF - PFD, r1 + 9);   // inner blocks: i0 >= inner_lo, i0 + 7 < inner_hi (the loads reach PFD rows ahead)
+    int i0 = S;
+    for (; i0 < nsteps && !(strip_inner && i0 >= inner_lo && i0 + 7 < inner_hi); i0 += 8)
+        static_for<0, 8>([&](auto P_) { row_step(std::false_type{}, P_, i0 + decltype(P_)::value); });
+    for (; i0 < nsteps && strip_inner && i0 + 7 < inner_hi; i0 += 8)
+        static_for<0, 8>([&](auto P_) { row_step(std::true_type{}, P_, i0 + decltype(P_)::value); });
+    for (; i0 < nsteps; i0 += 8)
+        static_for<0, 8>([&](auto P_) { row_step(std::false_type{}, P_, i0 + decltype(P_)::value); });
+    if constexpr (Q16OUT && !START4 && !U16) bad |= (chk_max > 35838u ? 1u : 0u) | chk_or;
     if (tb) {
         // table mode: [f][0][col] = first valid row (rows - 1 for an empty column, whose last row gets the 100 of LO :110, :125-127),
         // [f][1][col] = last valid row (same).  With bands every band leaves its own slot [f][band][.][col] as found (INT_MAX / -1
