@@ -96,7 +96,21 @@ __device__ __forceinline__ void u_row_scans2(unsigned a, unsigned& pa, unsigned&
 #define DCMT_QCX(a, b)   { const unsigned lo_ = qmin(v[a], v[b]); v[b] = qmax(v[a], v[b]); v[a] = lo_; }
 #define DCMT_QCMIN(a, b) { v[a] = qmin(v[a], v[b]); }
 #define DCMT_QCMAX(a, b) { v[b] = qmax(v[a], v[b]); }
-__device__ __forceinline__ void q_sort5(unsigned (&v)[5]) { DCMT_SORT5_NET(DCMT_QCX, DCMT_QCMIN, DCMT_QCMAX) }
+// sort5 with the three-input instructions: (a, b, c) = sort3(v0, v1, v2) as min3 / max3 and the middle one as the XOR of the five (a
+// multiset identity, exact on bit patterns, ties included: v_bitop3_b32 0x96), (d, e) = sort2(v3, v4), then the merge of 3 + 2 by rank:
+//     s0 = min(a, d)   s1 = min3(max(a, d), b, e)   s3 = max3(min(c, e), b, d)   s4 = max(c, e)   s2 = XOR of the five inputs and the other four
+// 10 min / max + 5 XORs (3.9 cycles each, tools/pk3_probe.hip) instead of 18 min / max.  Checked exhaustively against sorted() on
+// five values of five levels (tests/test_lane_schemes.py restates it).
+__device__ __forceinline__ unsigned xor3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ void q_sort5(unsigned (&v)[5])
+{
+    const unsigned a = hmin3(v[0], v[1], v[2]), c = hmax3(v[0], v[1], v[2]), t = xor3(v[0], v[1], v[2]), b = xor3(t, a, c);
+    const unsigned d = hmin2(v[3], v[4]), e = hmax2(v[3], v[4]);
+    const unsigned s0 = hmin2(a, d), s4 = hmax2(c, e);
+    const unsigned s1 = hmin3(hmax2(a, d), b, e), s3 = hmax3(hmin2(c, e), b, d);
+    const unsigned s2 = xor3(xor3(t, v[3], v[4]), xor3(s0, s1, s3), s4);
+    v[0] = s0; v[1] = s1; v[2] = s2; v[3] = s3; v[4] = s4;
+}
 __device__ __forceinline__ void q_merge55(const unsigned (&a)[5], const unsigned (&b)[5], unsigned (&P)[10])
 {
     constexpr int out[10] = DCMT_MERGE55_OUT;
@@ -265,7 +279,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
     }
     unsigned vpa = xa0, vpb = xb0, x7_prev = xa0;
     int before = 0, after = 0;
-    unsigned pend_v = xa0, pend_f1 = 0, pend_f2 = 0, pend_f3 = 0, pend_f4 = 0;
+    unsigned pend_v = xa0, pend_f1 = 0, pend_f2 = 0;
     unsigned long long pend_hme = 0, pend_hmo = 0;
     unsigned nxt_c = xa0, nxt_a = xa0, nxt_b = xb0;
 
@@ -280,7 +294,7 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
         const int o = t - 31;
         unsigned x7 = pend_v;
         if ((pend_hme | pend_hmo) != 0ull) {
-            const unsigned d = umax2(pend_f1, pend_f2) | (umax2(pend_f3, pend_f4) << 16);
+            const unsigned d = qmax(pend_f1, pend_f2);
             const bool he = __builtin_amdgcn_inverse_ballot_w64(pend_hme), ho = __builtin_amdgcn_inverse_ballot_w64(pend_hmo);
             const unsigned m = (he ? 0xffffu : 0u) | (ho ? 0xffff0000u : 0u);
             x7 = (d & m) | (pend_v & ~m);
@@ -344,10 +358,11 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
                 px = u_row_shr1(pa); sx = u_row_shl1(sa);
                 so = umax2(od, sx); pe = umax2(e, px);
             }
-            pend_f1 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)so);
-            pend_f2 = (unsigned)__builtin_amdgcn_ds_bpermute(a_p8, (int)px);
-            pend_f3 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)sx);
-            pend_f4 = (unsigned)__builtin_amdgcn_ds_bpermute(a_p8, (int)pe);
+            // out_E(l) = max(SO(l-8), PX(l+8)), out_O(l) = max(SX(l-8), PE(l+8)): the two values a lane fetches from lane l-8 ride in one
+            // word (SO low, SX high), so do the two from lane l+8 (PX low, PE high) -- two ds_bpermutes, not four, and their packed maximum
+            // is the pair (out_E, out_O) as it is needed
+            pend_f1 = (unsigned)__builtin_amdgcn_ds_bpermute(a_m8, (int)(so | (sx << 16)));
+            pend_f2 = (unsigned)__builtin_amdgcn_ds_bpermute(a_p8, (int)(px | (pe << 16)));
         }
         pend_v = v;
         pend_hme = vme; pend_hmo = vmo;

@@ -63,3 +63,34 @@ def test_fp_pair_shared_sort_matches_sorted():
         for x, want in ((el, sorted((el, a, e, o, d))), (orr, sorted((a, e, o, d, orr)))):
             got = [min(x, s[0]), med3(x, s[0], s[1]), med3(x, s[1], s[2]), med3(x, s[2], s[3]), max(x, s[3])]
             assert got == want
+
+
+def test_sort5_from_three_input_minima_maxima_and_xors():
+    """q_sort5 (csrc/dcmt_kernels_fp_q16.h): sort3 of three values as min3 / max3 / XOR, sort2 of the other two, the merge of 3 + 2 by
+    rank, the middle one as the XOR of all five and the other four.  Exhaustive on five values of five levels (every tie pattern)."""
+    def sort5x(v):
+        v0, v1, v2, v3, v4 = v
+        a, c, t = min(v0, v1, v2), max(v0, v1, v2), v0 ^ v1 ^ v2
+        b = t ^ a ^ c
+        d, e = min(v3, v4), max(v3, v4)
+        s0, s4 = min(a, d), max(c, e)
+        s1, s3 = min(max(a, d), b, e), max(min(c, e), b, d)
+        return [s0, s1, (t ^ v3 ^ v4) ^ (s0 ^ s1 ^ s3) ^ s4, s3, s4]
+    for v in itertools.product((3, 1029, 7000, 7001, 31743), repeat=5):
+        assert sort5x(v) == sorted(v), v
+
+
+def test_k_fp_h_stage_windows_cover_31_columns():
+    """k_fp_h (csrc/dcmt_kernels_fp_h16.h): W3 -> W7 -> W19 -> out through column shifts (1, 2), (2, 4), (6, 12), (-15, -3): the closing
+    maximum is the 31-wide window centred on the column, and the values an output of the strip's 128 columns depends on lie inside the
+    160 columns the stage arrays hold."""
+    rng = np.random.default_rng(9)
+    n = 160 + 32
+    for _ in range(50):
+        v0 = rng.integers(0, 1000, size=n)
+        w3 = np.array([v0[c:c + 3].max() for c in range(n - 2)])
+        w7 = np.array([max(w3[c], w3[c + 2], w3[c + 4]) for c in range(len(w3) - 4)])
+        w19 = np.array([max(w7[c], w7[c + 6], w7[c + 12]) for c in range(len(w7) - 12)])
+        for c in range(16, 16 + 128):                       # array slot of the strip's columns
+            assert max(w19[c - 15], w19[c - 3]) == v0[c - 15:c + 16].max()
+            assert c + 15 < 160 and c - 15 >= 1
