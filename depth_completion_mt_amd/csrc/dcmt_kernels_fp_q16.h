@@ -25,6 +25,7 @@
 #pragma once
 
 #include "dcmt_kernels_fp_pair.h"
+#include "median_pk3_nets.h"
 
 namespace dcmt {
 
@@ -123,13 +124,12 @@ __device__ __forceinline__ void q_merge55(const unsigned (&a)[5], const unsigned
 }
 __device__ __forceinline__ void q_mid20(const unsigned (&pa)[10], const unsigned (&pb)[10], unsigned (&C)[6])
 {
-    constexpr int out[6] = DCMT_MID20_OUT;
-    unsigned v[20];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) { v[k] = pa[k]; v[10 + k] = pb[k]; }
-    DCMT_MID20_NET(DCMT_QCX, DCMT_QCMIN, DCMT_QCMAX)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) C[k] = v[out[k]];
+    // (median_pk3_nets.h: the two-input network with two of its exchanges folded into min3 / max3)
+#define DCMT_IN_(k) ((k) < 10 ? pa[(k) < 10 ? (k) : 0] : pb[(k) >= 10 ? (k) - 10 : 0])
+#define DCMT_OUT_(k) C[k]
+    DCMT_MID20_PK3(DCMT_IN_, DCMT_OUT_)
+#undef DCMT_IN_
+#undef DCMT_OUT_
 }
 #undef DCMT_QCX
 #undef DCMT_QCMIN

@@ -31,14 +31,14 @@
  * The reference's own result for such pixels depends on the min/max flavour of the OpenCV
  * build (SIMD vs scalar), so there is nothing to be bit-exact with.  -0.0 is treated as 0.0.
  *
- * Depth grids: frames whose depths are all multiples of 1/256 m below 256 m -- what a KITTI depth PNG / 256 holds,
+ * Depth grids: frames whose depths are all multiples of 1/256 m below 120 m -- what a KITTI depth PNG / 256 holds,
  * DC_lidar_only/main.cpp:75-82 -- let large device batches keep their intermediate image as 16-bit integers.  The library
  * finds that out itself on the device (and repeats the step with its f32 kernels when a frame turns out otherwise); results
  * are the same bits either way, and no promise about the values is asked of the caller.  What it costs when the depths are NOT
  * such multiples: a call that makes the attempt runs both of its large kernels twice (the 16-bit attempt, then the f32 kernels
  * behind the flag the attempt raised), and the context then skips the attempt for its next 63 calls before trying once more --
- * arbitrary f32 depths pay one double run in 64 calls.  Depths beyond 119.99 m (inverted values below -20 m: outside the 15-bit code
- * range) count as "not on the grid" as well.
+ * arbitrary f32 depths pay one double run in 64 calls.  Depths beyond 119.996 m (inverted values below -20 m: outside the 15-bit code
+ * range) count as "not on the grid" as well, also on the uint16 entry point (payloads above 30719).
  *
  * In place: d_dst may be d_src (the reference's function is in place by signature: dense = sparse.clone(), :27), or overlap
  * it; the library then never takes the 16-bit attempt (its f32 kernels read src completely before dst is first written).
