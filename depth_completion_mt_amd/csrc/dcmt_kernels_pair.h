@@ -236,6 +236,8 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
                 const float re = __builtin_fmaf(raw.e, 256.0f, -__fsub_rn(te, kMg)), ro = __builtin_fmaf(raw.o, 256.0f, -__fsub_rn(to, kMg));
                 chk_max = max(max(chk_max, __builtin_bit_cast(unsigned, te) - kBase), __builtin_bit_cast(unsigned, to) - kBase);
                 chk_or |= __builtin_bit_cast(unsigned, re) | __builtin_bit_cast(unsigned, ro);
+                asm volatile("" : "+v"(chk_max), "+v"(chk_or));          // here, not "some time in this block of eight": left to itself the scheduler
+                                                                         // defers the check and keeps the raw rows of all eight steps alive (+22 VGPRs)
             }
             // ---- H2 on load (LO :55-67); outside the image: the dilate border value
             F2 x2 = {invert_valid(raw.e, max_depth, thr), invert_valid(raw.o, max_depth, thr)};
