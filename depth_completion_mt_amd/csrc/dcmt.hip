@@ -79,6 +79,10 @@ struct dcmt_ctx {
     int* q16_seen = nullptr;          // pinned host word (and its device address) the same kernel sets: the NEXT calls skip the 16-bit attempt
     int* q16_seen_dev = nullptr;
     int q16_skip = 0;                 // calls left without an attempt (after a raised flag: 63, then one more try)
+    unsigned* winner = nullptr;       // N2: the winner plane of dcmt_project_points_dev (tags: generation | point index), allocated by its first call
+    size_t winner_elems = 0;
+    int winner_bits = 0;              // index bits of the plane's tag layout
+    unsigned winner_gen = 0;          // generation of the last call (0: the plane is all zeros and nothing has been written)
     int* bb_min = nullptr;            // LC fast path: per (frame, label) bounding boxes, grown on demand
     int* bb_max = nullptr;
     size_t bb_ints = 0;
@@ -822,7 +826,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     (void)hipFree(ctx->x6q); (void)hipFree(ctx->q16_bad); if (ctx->q16_seen) (void)hipHostFree(ctx->q16_seen);
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_lab);
-    (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max);
+    (void)hipFree(ctx->bb_min); (void)hipFree(ctx->bb_max); (void)hipFree(ctx->winner);
     (void)hipFree(ctx->slic_cells); (void)hipFree(ctx->slic_centers[0]); (void)hipFree(ctx->slic_centers[1]);
     (void)hipFree(ctx->slic_sums);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -887,17 +891,35 @@ int dcmt_project_points_dev(dcmt_ctx* ctx, const float* d_points, const int32_t*
     ProjMats M;
     std::memcpy(M.T, T, sizeof(float) * 12);       // the bottom row of T is never used (SL :483-485)
     std::memcpy(M.P, P, sizeof(float) * 12);
-    int* winner = reinterpret_cast<int*>(ctx->pp[0]);   // scratch the cascade only touches after its own first kernel
+    // the winner plane: tags of generation g = (g << idx_bits) | point index, g >= 1 (0 = the cleared plane).  It is cleared when it
+    // is (re)allocated, when a call needs more index bits than its layout has, and when the generations run out.
     const size_t n_px = (size_t)batch * rows * cols;
-    DCMT_HIP(ctx, hipMemsetAsync(winner, 0xFF, sizeof(int) * n_px, st));          // -1 = no point
+    int need_bits = 1;
+    while (need_bits < 31 && ((size_t)1 << need_bits) <= (size_t)n_points) ++need_bits;
+    if (need_bits > 30) return DCMT_E_INVALID;                             // (2^30 points per call: 16 GiB of records)
+    if (n_px > ctx->winner_elems) {
+        (void)hipFree(ctx->winner); ctx->winner = nullptr; ctx->winner_elems = 0;
+        DCMT_HIP(ctx, hipMalloc((void**)&ctx->winner, sizeof(unsigned) * n_px));
+        ctx->winner_elems = n_px; ctx->winner_bits = 0; ctx->winner_gen = 0;
+    }
+    const bool relayout = need_bits > ctx->winner_bits;
+    if (relayout) ctx->winner_bits = need_bits < 24 ? 24 : need_bits;       // (room for 16 M points per call before the next re-layout)
+    const unsigned gen_max = (1u << (32 - ctx->winner_bits)) - 1u;
+    if (relayout || ctx->winner_gen == 0 || ctx->winner_gen >= gen_max) {
+        DCMT_HIP(ctx, hipMemsetAsync(ctx->winner, 0, sizeof(unsigned) * ctx->winner_elems, st));
+        ctx->winner_gen = 0;
+    }
+    const unsigned gen_tag = ++ctx->winner_gen << ctx->winner_bits;
+    unsigned* winner = ctx->winner;
     if (n_points > 0)
         hipLaunchKernelGGL(k_project_scatter, dim3((n_points + 255) / 256), dim3(256), 0, st, d_points, d_offsets, n_points, batch, M,
-                           winner, rows, cols);
-    const size_t fe = (size_t)rows * cols;
-    if (fe % 2 == 0 && (uintptr_t)d_sparse % 8 == 0)
-        hipLaunchKernelGGL(k_project_resolve<2>, dim3((unsigned)((fe / 2 + 255) / 256), batch), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
+                           winner, rows, cols, gen_tag);
+    if (n_px % 4 == 0 && (uintptr_t)d_sparse % 16 == 0)
+        hipLaunchKernelGGL(k_project_resolve<4>, dim3((unsigned)((n_px / 4 + 255) / 256)), dim3(256), 0, st, d_points, M, winner, d_sparse, n_px, gen_tag, ctx->winner_bits);
+    else if (n_px % 2 == 0 && (uintptr_t)d_sparse % 8 == 0)
+        hipLaunchKernelGGL(k_project_resolve<2>, dim3((unsigned)((n_px / 2 + 255) / 256)), dim3(256), 0, st, d_points, M, winner, d_sparse, n_px, gen_tag, ctx->winner_bits);
     else
-        hipLaunchKernelGGL(k_project_resolve<1>, dim3((unsigned)((fe + 255) / 256), batch), dim3(256), 0, st, d_points, d_offsets, M, winner, d_sparse, rows, cols, batch);
+        hipLaunchKernelGGL(k_project_resolve<1>, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, st, d_points, M, winner, d_sparse, n_px, gen_tag, ctx->winner_bits);
     DCMT_HIP(ctx, hipGetLastError());
     return DCMT_OK;
 }
