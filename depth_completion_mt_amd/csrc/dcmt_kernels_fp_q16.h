@@ -2,24 +2,31 @@
 // frame the reference's lidar-only and lidar-camera callers feed the path is a uint16 PNG payload / 256, LO/main.cpp:75-82).
 //
 // H2..H9 only ever SELECT values (max, min, median), so on such a frame every value of X2..X9 is one of
-//     j / 256,   j in [-39935, 25600]        (an empty pixel k / 256 with k < 26, an inverted depth (25600 - k) / 256, or the 100
+//     j / 256,   j in [-5119, 25600]         (an empty pixel k / 256 with k < 26, an inverted depth (25600 - k) / 256, or the 100
 //                                             of a column without valid pixels, LO :110)
-// -- with max_depth = 100 and thr = 0.1 (the reference's constants; other values run the f32 kernels).  code = j + 39935 is a
-// 16-bit unsigned integer, the map is strictly increasing, so maxima / minima / medians of codes are the codes of the f32
-// results, and a hole (x < 0.1f) is code <= 39960.  Two adjacent columns then fit ONE register (low half = column 2l, high
-// half = column 2l + 1) and v_pk_max_u16 / v_pk_min_u16 work on both at the price of one v_max_f32: what k_fp_p
-// (dcmt_kernels_fp_pair.h) gains from two columns per lane, without its doubled register state -- this kernel keeps k_fp_s's
-// occupancy.  gfx950 has no packed three-input min / max / med3, so the median runs the two-input networks of
-// median_shared_nets.h: 18 + (26 + 36) / 2 + 10 = 59 packed instructions per row for two columns (k_fp_s: 38.5 per column), and
-// the five sorted neighbours of BOTH columns are one DPP shift each way plus two v_alignbit (4 instead of 2 x 4 moves).
+// -- with max_depth = 100 and thr = 0.1 (the reference's constants; other values run the f32 kernels).  code = j + 6143 (Q16,
+// dcmt_kernels_fused.h) is 0x0400 .. 0x7bff: the map is strictly increasing, so maxima / minima / medians of codes are the codes of the
+// f32 results, and a hole (x < 0.1f) is code <= 6168.  Two adjacent columns then fit ONE register (low half = column 2l, high half =
+// column 2l + 1) and packed instructions work on both at the price of one v_max_f32: what k_fp_p (dcmt_kernels_fp_pair.h) gains from two
+// columns per lane, without its doubled register state -- this kernel keeps 3 waves per SIMD.
+//
+// Which packed instructions: the code range is the bit patterns of the positive NORMAL half-floats, which order as f16 exactly as they
+// do as u16.  gfx950 has packed two-input minima / maxima for u16 AND packed THREE-input ones for f16 (v_pk_maximum3_f16 /
+// v_pk_minimum3_f16, VOP3P, new on gfx950; tools/pk3_probe.hip: exact on these patterns, one v_pk_max_u16's issue cost) -- but no packed
+// med3 of any type.  (Round 2 wrote "no packed three-input min / max" here; that was wrong.)  So: the vertical 31-row maximum is 4
+// three-input instructions per register instead of 6; the median keeps its two-input MERGE55 (26), takes MID20 with two exchanges folded
+// (34, median_pk3_nets.h), sort5 from min3 / max3 and XORs (10 + 5), the closing selection with its minimum in two min3 (8): 53 + 4
+// neighbour moves per row for two columns (k_fp_s: 38.5 per column with v_med3_f32).  The three-input networks of
+// median_shared_nets3.h are half med3 and gain nothing here: a med3 emulated from min3 + max3 + two XORs (or two v_med3_f16 on the
+// halves) costs what the exchange it replaces costs.
 // The median is converted back (code -> f32 is exact: one v_cvt and one fused multiply-add) and the Gaussian, the masked select
 // and the final invert are the f32 code of k_fp_p (PostPipeP::after_median), so the output is bit-identical to k_fp_s's.
 //
-// Fill: the vertical 31-maximum runs packed (6 two-input instructions for 128 columns); the horizontal one, on rows that have
-// a hole, unpacks the two halves and is k_fp_p's scheme on unsigned integers (0 is the neutral element; register B holds the
-// 30 halo columns unpacked, one per lane).
+// Fill: the vertical 31-maximum runs packed; the horizontal one, on rows that have a hole, unpacks the two halves and is k_fp_p's
+// scheme on unsigned integers (0 is the neutral element; register B holds the 30 halo columns unpacked, one per lane), with the two
+// values a lane fetches from lane l - 8 in one word and the two from lane l + 8 in another: two ds_bpermutes.
 //
-// X6U16 = true: X6 arrives as the codes themselves (k_pre_p<Q16OUT>, which has checked every value it stored and raised a flag
+// X6U16 = true: X6 arrives as the codes themselves (k_pre_p<Q16OUT>, which has checked the frame's values and raised a flag
 // otherwise -- dcmt.hip reruns the f32 kernels behind that flag, so what this kernel makes of a frame that is no grid is never
 // looked at).  X6U16 = false (X6 as f32, converted while loading) was the first stage of this work and is kept for experiments.
 #pragma once
@@ -92,8 +99,8 @@ __device__ __forceinline__ void u_row_scans2(unsigned a, unsigned& pa, unsigned&
 #undef DCMT_U2
 }
 
-// The exact 5x5 median of dcmt_median.h on packed pairs: the two-input networks of median_shared_nets.h (the three-input
-// forms need v_min3 / v_max3 / v_med3, which have no packed 16-bit version).
+// The exact 5x5 median of dcmt_median.h on packed pairs: the two-input MERGE55 of median_shared_nets.h (the three-input forms
+// need a packed med3, which does not exist), MID20 from median_pk3_nets.h, sort5 and the closing selection below.
 #define DCMT_QCX(a, b)   { const unsigned lo_ = qmin(v[a], v[b]); v[b] = qmax(v[a], v[b]); v[a] = lo_; }
 #define DCMT_QCMIN(a, b) { v[a] = qmin(v[a], v[b]); }
 #define DCMT_QCMAX(a, b) { v[b] = qmax(v[a], v[b]); }

@@ -84,7 +84,7 @@ def _grid_frame(g, rows, cols):
     kind = g.integers(0, 4)
     if kind == 1:       # around the threshold (25 / 26), around max_depth (25600), the largest payload (65535)
         m = g.random((rows, cols)) < 0.03
-        k[m] = g.choice(np.array([1, 25, 26, 27, 25599, 25600, 25601, 40000, 65535]), int(m.sum()))
+        k[m] = g.choice(np.array([1, 25, 26, 27, 25599, 25600, 25601, 30719, 30720, 40000, 65535]), int(m.sum()))
     elif kind == 2:
         k[:, g.integers(0, cols):] = 0
         k[: g.integers(0, rows)] = 0
