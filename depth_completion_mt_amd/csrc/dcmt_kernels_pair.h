@@ -157,36 +157,42 @@ void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
     bool warm0 = false;
     if (band > 0) S = max(r0 - 18, 0) & ~7;
     else {
-        // 16-row chunks, two in flight: the scan is a chain of dependent round trips to memory, one per chunk
+        // CH-row chunks, two in flight: the scan is a chain of dependent round trips to memory, one per chunk; the two chunks in flight when
+        // the first valid row turns up are read again by the stream (2 * CH rows per wave).  Measured, CH = 16 / 8 / 4 / 2: k_pre_p 0.597 / 0.573-0.583 /
+        // 0.585-0.61 / 0.585-0.62 ms per 1024 frames, 2.08 / 1.92 / 1.88 GB read
+#ifndef DCMT_SCAN_CH
+#define DCMT_SCAN_CH 8
+#endif
+        constexpr int CH = DCMT_SCAN_CH;
         bool zeros = true;                                           // every chunk above zv held nothing but 0.0
-        auto valid16 = [&](const F2 (&v)[16]) -> bool {
+        auto valid16 = [&](const F2 (&v)[CH]) -> bool {
             // the bit patterns are OR-ed (v_or3_b32): "exactly +0.0 everywhere" is a statement about bits -- rows holding a -0.0 take the
             // cold start (the warm start would seed the rings with +0.0)
             float m = fmax2(v[0].e, v[0].o);
             unsigned ob = __builtin_bit_cast(unsigned, v[0].e) | __builtin_bit_cast(unsigned, v[0].o);
 #pragma unroll
-            for (int q = 1; q < 16; q += 1) { m = fmax3(m, v[q].e, v[q].o); ob = ob | __builtin_bit_cast(unsigned, v[q].e) | __builtin_bit_cast(unsigned, v[q].o); }
+            for (int q = 1; q < CH; q += 1) { m = fmax3(m, v[q].e, v[q].o); ob = ob | __builtin_bit_cast(unsigned, v[q].e) | __builtin_bit_cast(unsigned, v[q].o); }
             const bool valid = __builtin_amdgcn_ballot_w64(m >= thr) != 0ull;
             if (!valid) zeros = zeros && __builtin_amdgcn_ballot_w64(ob != 0u) == 0ull;
             return valid;
         };
-        auto load16 = [&](F2 (&v)[16], int z) {
+        auto load16 = [&](F2 (&v)[CH], int z) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < CH; ++q) {
                 F2 x = load_row(min(z + q, rows - 1));
                 if constexpr (NORM) x = {norm_apply(x.e, na, nb), norm_apply(x.o, na, nb)};
                 v[q] = x;
             }
         };
-        F2 va[16], vb[16];
+        F2 va[CH], vb[CH];
         int zv = r1;
         load16(va, 0);
-        for (int z = 0; z < r1; z += 32) {
-            load16(vb, z + 16);
+        for (int z = 0; z < r1; z += 2 * CH) {
+            load16(vb, z + CH);
             if (valid16(va)) { zv = z; break; }
-            if (z + 16 >= r1) break;
-            load16(va, z + 32);
-            if (valid16(vb)) { zv = z + 16; break; }
+            if (z + CH >= r1) break;
+            load16(va, z + 2 * CH);
+            if (valid16(vb)) { zv = z + CH; break; }
         }
         warm0 = !START4 && zeros && zv >= 32 && zv < r1;
         S = warm0 ? zv : max(zv - DZ, 0) & ~7;
