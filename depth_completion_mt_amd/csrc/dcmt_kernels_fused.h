@@ -1151,22 +1151,30 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     }
     // steps 32..rows+34: fill + post; post step u = t - FpS::LAG takes X7 row u - 2 = t - 31, the row this step's fill front end returns
     const int nsteps = rows + 35;
-    for (int t0 = 32; t0 < nsteps; t0 += 16) {
-        static_for<0, 16>([&](auto P_) {
-            constexpr int p = decltype(P_)::value;
-            const int t = t0 + p, u = t - FpS::LAG;
-            const float x7 = fill_step(P_, t);
-            pipe.template step<((p + 3) & 7)>(x7, u);
-            if constexpr (p == 3) {
-                // u == 6: output row 0 of the shifted frame (image row V) has just been stored; the V rows above it are equal
-                if (t0 == 32 && V > 0) {
-                    FrameBuf top;
-                    top.init(dst + fo, (size_t)V * cols);
-                    const unsigned tb = pipe.outlane ? pipe.ob : kDropOffset;
-                    for (int r = 0; r < V; ++r) top.st(tb, r, cols, pipe.last_out);
-                }
+    int t0 = 32;
+    auto main_step = [&](auto P_) {
+        constexpr int p = decltype(P_)::value;
+        const int t = t0 + p, u = t - FpS::LAG;
+        const float x7 = fill_step(P_, t);
+        pipe.template step<((p + 3) & 7)>(x7, u);
+        if constexpr (p == 3) {
+            // u == 6: output row 0 of the shifted frame (image row V) has just been stored; the V rows above it are equal
+            if (t0 == 32 && V > 0) {
+                FrameBuf top;
+                top.init(dst + fo, (size_t)V * cols);
+                const unsigned tb = pipe.outlane ? pipe.ob : kDropOffset;
+                for (int r = 0; r < V; ++r) top.st(tb, r, cols, pipe.last_out);
             }
-        });
+        }
+    };
+    for (; t0 < nsteps; t0 += 16) {                                  // (four quarters with a way out behind each: see k_fp_q)
+        static_for<0, 4>(main_step);
+        if (t0 + 4 >= nsteps) break;
+        static_for<4, 8>(main_step);
+        if (t0 + 8 >= nsteps) break;
+        static_for<8, 12>(main_step);
+        if (t0 + 12 >= nsteps) break;
+        static_for<12, 16>(main_step);
     }
     if (lane == 0) {
         if (before) atomicAdd(&cnt[0], before);
