@@ -31,7 +31,7 @@ struct dcmt_ctx {
     int max_rows = 0, max_cols = 0, max_batch = 0;
     size_t frame_elems = 0;           // max_rows * max_cols
     // device scratch
-    float* x5 = nullptr;              // [max_batch][rows][cols] : cascade after the small fill
+    float* x5 = nullptr;              // [max_batch][rows][cols] : cascade after the small fill (= pp[1], see dcmt_create)
     float* pp[2] = {nullptr, nullptr};// ping-pong of the large-fill applications
     int* colstat = nullptr;           // [max_batch][tile rows][2][cols]  (staged path)
     int* counters = nullptr;          // [max_batch][kCntStride]
@@ -518,7 +518,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
             }
             DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_min, 0x7f, sizeof(int) * need, st));
             DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_max, 0xff, sizeof(int) * need, st));
-            float* x4 = stop == DCMT_STAGE_CLOSE5 ? d_dst : ctx->pp[1];
+            float* x4 = stop == DCMT_STAGE_CLOSE5 ? d_dst : ctx->pp[0];       // (dead before the redo chain writes pp[0]; x5 shares pp[1])
             const dim3 bg((cols + 63) / 64, (rows + kBboxRows - 1) / kBboxRows, batch);
             const size_t table = sizeof(int) * 4 * (size_t)n_labels;
             if (table <= 48 * 1024 && !std::getenv("DCMT_BBOX_GLOBAL"))
@@ -576,8 +576,8 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
         }
         if (d_src16) {   // the staged kernels take f32: convert into scratch that nothing writes before they have read it
             const size_t n = (size_t)batch * rows * cols;
-            hipLaunchKernelGGL(k_u16_to_f32, dim3(1024), dim3(256), 0, st, d_src16, ctx->pp[1], n, in_scale);
-            d_src = ctx->pp[1];
+            hipLaunchKernelGGL(k_u16_to_f32, dim3(1024), dim3(256), 0, st, d_src16, ctx->pp[0], n, in_scale);
+            d_src = ctx->pp[0];
         }
     }
     ctx->last_stream = st;
@@ -796,9 +796,12 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     auto fail = [&](int rc) { dcmt_destroy(ctx); return rc; };
     if (dev_guard_.rc != DCMT_OK) return fail(dev_guard_.rc);
     const size_t plane = sizeof(float) * ctx->frame_elems * (size_t)max_batch;
-    if (hipMalloc((void**)&ctx->x5, plane) != hipSuccess) return fail(DCMT_E_NOMEM);
+    // two planes: X6 (x5) is dead once the first fill application of the hole-closure loop has read it, and that application writes pp[0], so
+    // x5 shares pp[1] (the second application's output); X4 of the label-masked stage and the staged kernels' uint16 conversion live in
+    // pp[0], which nothing writes before they have been read
     if (hipMalloc((void**)&ctx->pp[0], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
+    ctx->x5 = ctx->pp[1];
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->q16_bad, 256) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->q16_seen, 64, hipHostMallocMapped) != hipSuccess) return fail(DCMT_E_NOMEM);
@@ -821,7 +824,7 @@ void dcmt_destroy(dcmt_ctx* ctx)
     if (!ctx) return;
     DeviceGuard dev_guard_(ctx);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
-    (void)hipFree(ctx->x5); (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
+    (void)hipFree(ctx->pp[0]); (void)hipFree(ctx->pp[1]);
     (void)hipFree(ctx->colstat); (void)hipFree(ctx->counters); (void)hipFree(ctx->tb);
     (void)hipFree(ctx->x6q); (void)hipFree(ctx->q16_bad); if (ctx->q16_seen) (void)hipHostFree(ctx->q16_seen);
     (void)hipFree(ctx->norm_stats); (void)hipFree(ctx->norm_coef);

@@ -138,7 +138,7 @@ typedef struct {
 int dcmt_device_count(void);
 
 /* Creates a context on `device` able to process up to max_batch frames of up to
- * max_rows x max_cols per call.  Allocates the device scratch every path needs up front (12 B per
+ * max_rows x max_cols per call.  Allocates the device scratch every path needs up front (8 B per
  * pixel per frame of max_batch); two buffers only one path uses are allocated by the first call that takes it and kept (the
  * 16-bit plane of large on-grid batches, 2 B per pixel; the column statistics of the small-batch tile kernels), so no call
  * after the first of its kind allocates.  A frame may hold at most 2^29 - 16 pixels (it is addressed with 32-bit byte offsets
