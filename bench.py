@@ -181,6 +181,28 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
     out["4_per_gpu_share"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {b128} frames per step (the per-GPU shard of 1024 frames on 8 GPUs)",
                               "value": b128 * 1e3 / ms, "unit": "frames/s", "kernels": c4.last_path(), "roofline": hbm_roofline(b128 * BYTES_PER_FRAME, ms)}
     c4.close()
+    # the same 128 frames as two contexts x 64 frames on two streams, never joined: what a rank that streams its shard through two
+    # contexts gets (one call's tail under the next call's head; the stream-ordered single call above cannot have that)
+    if b128 >= 2:
+        h = b128 // 2
+        cs2 = [Context(local_rank, ROWS, COLS, h) for _ in range(2)]
+        ss2 = [torch.cuda.Stream() for _ in range(2)]
+        def two():
+            for k2 in range(2):
+                cs2[k2].complete_dev(d_src[k2 * h:(k2 + 1) * h], d_dst[k2 * h:(k2 + 1) * h], params, stream=ss2[k2].cuda_stream)
+        for _ in range(40):
+            two()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            two()
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / 200 * 1e3
+        out["4_per_gpu_share_in_flight"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {2 * h} frames per step as 2 contexts x {h} frames on 2 streams, never joined; "
+                                                        "40 untimed + 200 timed steps, host clock around a device synchronise",
+                                            "value": 2 * h * 1e3 / ms2, "unit": "frames/s", "roofline": hbm_roofline(2 * h * BYTES_PER_FRAME, ms2)}
+        for c in cs2:
+            c.close()
     # the same step on frames that are NOT multiples of 1/256 m (every depth scaled by 1.001): the 16-bit form of X6 does not apply, the
     # first call pays the attempt and the f32 rerun, the following ones go straight to the f32 kernels (k_pre_p -> k_fp_s) -- the
     # rate a caller with arbitrary f32 depths gets
