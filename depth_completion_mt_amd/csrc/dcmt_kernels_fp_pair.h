@@ -170,6 +170,51 @@ struct PostPipeP {
             }
         }
     }
+
+    // The same for k_fp_q's packed medians m = (code_E, code_O) where BLUR && FILLED && GRID: IN EXACT ARITHMETIC.  A code is an integer
+    // below 2^15, value = (code - 6143) / 256.  The horizontal pass of the reference order  c*k0 + s1*k1 + s2*k2  on such values only
+    // ever forms multiples of 2^-12 below 128 (19 bits), the vertical pass multiples of 2^-16 below 128 (23 bits), and the final
+    // 100 - value is a multiple of 2^-16 below 128 too: no operation of the oracle's sequence rounds, so any other sequence
+    // without a rounding gives the same bits.  This one works on the codes as integer-valued floats with the weights 1 4 6 4 1
+    // (horizontal sums <= 16 * 31743 < 2^19, vertical <= 256 * 31743 < 2^23) and scales once at the end:
+    //     out = 100 - (N / 65536 - 6143 / 256) = fma(N, -2^-16, 123.99609375).
+    // Horizontal, two columns per lane, four lane shifts (each folded into an add):  S1 = O[l-1] + O,  S2 = E + E[l+1],
+    //     G_E = 4 (E + S1) + (S2[l-1] + S2) = 6 E + 4 (O[l-1] + O) + E[l-1] + E[l+1],   G_O = 4 (O + S2) + (S1 + S1[l+1]):
+    // 2 conversions + 8 + 2 * 4 + 2 instructions per row step instead of 4 + 14 + 10 + 2.
+    template <int PP>
+    __device__ __forceinline__ void after_median_codes(unsigned m, int u)
+    {
+        static_assert(BLUR && FILLED && GRID, "exact only on grid values; the select of LO :184 is not in here");
+        float ce = (float)(m & 0xffffu), co = (float)(m >> 16);
+        if (edge_strip) {
+            const float re = __shfl(ce, rle, 64), ro = __shfl(co, rlo, 64);
+            if (outside) { ce = re; co = ro; }
+        }
+        const float s1 = __fadd_rn(from_left(co), co), s2 = __fadd_rn(ce, from_right(ce));
+        const float ue = __fadd_rn(from_left(s2), s2), wo = __fadd_rn(from_right(s1), s1);
+        G1[(PP + 4) & 7] = {__builtin_fmaf(__fadd_rn(ce, s1), 4.0f, ue), __builtin_fmaf(__fadd_rn(co, s2), 4.0f, wo)};
+        const int o = u - 6;
+        if ((unsigned)o < (unsigned)rows) {
+            const float top = __fadd_rn(max_depth, (float)Q16::OFFSET * 0.00390625f);     // 100 + 6143 / 256: exact
+            auto finish = [&](F2 u1, F2 u2, F2 d1, F2 d2) {
+                const F2 g0 = G1[(PP + 2) & 7];
+                const float ne = __builtin_fmaf(g0.e, 6.0f, __builtin_fmaf(__fadd_rn(u1.e, d1.e), 4.0f, __fadd_rn(u2.e, d2.e)));
+                const float no = __builtin_fmaf(g0.o, 6.0f, __builtin_fmaf(__fadd_rn(u1.o, d1.o), 4.0f, __fadd_rn(u2.o, d2.o)));
+                const F2 val = {__builtin_fmaf(ne, -0x1p-16f, top), __builtin_fmaf(no, -0x1p-16f, top)};
+                st2(of, outlane ? ob : kDropOffset, o, cols, val);
+                last_out = val;
+            };
+            const F2 g_p2 = G1[(PP + 4) & 7], g_p1 = G1[(PP + 3) & 7], g_0 = G1[(PP + 2) & 7], g_m1 = G1[(PP + 1) & 7], g_m2 = G1[PP];
+            if (o < 2 || o + 2 >= rows) {                                // reflect-101 rows, as above
+                finish(o >= 1 ? g_m1 : g_p1,
+                       o >= 2 ? g_m2 : (o == 1 ? g_0 : g_p2),
+                       o + 1 < rows ? g_p1 : g_m1,
+                       o + 2 < rows ? g_p2 : (o + 2 == rows ? g_0 : g_m2));
+            } else {
+                finish(g_m1, g_m2, g_p1, g_p2);
+            }
+        }
+    }
 };
 
 // wave -> (frame, strip) for WPB waves per workgroup (wave_strip of dcmt_kernels_fused.h has 4)

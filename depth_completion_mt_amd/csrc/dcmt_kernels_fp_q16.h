@@ -382,7 +382,8 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
         unsigned s[5] = {rl, __builtin_amdgcn_alignbit(x, rl, 16), x, __builtin_amdgcn_alignbit(rr, x, 16), rr};
         q_sort5(s);
         const unsigned m = mc.template step<PP>(s);
-        pipe.template after_median<PP>(Q16::value(m & 0xffffu), Q16::value(m >> 16), u);
+        if constexpr (BLUR && FILLED) pipe.template after_median_codes<PP>(m, u);       // codes all the way: exact (PostPipeP)
+        else pipe.template after_median<PP>(Q16::value(m & 0xffffu), Q16::value(m >> 16), u);
     };
 
     // steps 0..31 (16..31 after a warm start): fill only.  The last of them returns X7 row 0, which the post pipeline takes three times
