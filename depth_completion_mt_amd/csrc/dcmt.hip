@@ -75,7 +75,9 @@ struct dcmt_ctx {
                                       // only pays from about one round of them on (measured, 352x1216, frames per call, whole step against the f32 kernels:
                                       // 128 -12 %, 256 +3 %, 512 +4 %, 1024 +5 %; threshold = 236 frames); env DCMT_Q16_MIN_WAVES
     unsigned short* x6q = nullptr;    // [max_batch][rows][cols] X6 as 16-bit codes (k_pre_p<Q16OUT> -> k_fp_q)
-    int* q16_bad = nullptr;           // raised by k_pre_p<Q16OUT> when a value it stored was not a code
+    int* q16_bad = nullptr;           // a ring of kQ16Flags flags; attempt n uses flag n % kQ16Flags: raised by k_pre_p<Q16OUT> when a value it stored was
+                                      // not a code, and cleared one attempt ahead by that kernel too (no memset in the stream)
+    unsigned q16_attempts = 0;
     int* q16_seen = nullptr;          // pinned host word (and its device address) the same kernel sets: the NEXT calls skip the 16-bit attempt
     int* q16_seen_dev = nullptr;
     int q16_skip = 0;                 // calls left without an attempt (after a raised flag: 63, then one more try)
@@ -180,6 +182,8 @@ int ensure_x6q(dcmt_ctx* ctx)
 }
 
 // grid of the kernels that deal (frame, strip) pairs to waves in one flat sequence (wave_strip in dcmt_kernels_fused.h)
+constexpr unsigned kQ16Flags = 64;
+
 dim3 wave_grid(int strips, int batch, int xcd_map)
 {
     return dim3(xcd_map ? 8 * (((batch / 8) * strips + 3) / 4) : (batch * strips + 3) / 4);
@@ -284,6 +288,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
         // table mode: only the k_fp_s path reads X6 through the per-column table (the probes and the unfused kernels get a fully written X6)
         int bands = 1;                      // row bands of k_pre_p = table slots per frame
         bool q16 = false;                   // this chunk's X6 is 16-bit codes (in ctx->x6q)
+        int* qbad = ctx->q16_bad;           // ... and the flag its attempt raises on a frame that has none
         int* tc = (stop == DCMT_STAGE_FINAL && ctx->fuse_fp && ctx->top_table) ? ctx->tb : nullptr;   // chunks follow each other in the stream: each may use the whole table
         {
             float* o6 = stop == DCMT_STAGE_EXTEND ? dst : x6;
@@ -309,17 +314,17 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 if (bands > rows / 32) bands = rows / 32 > 0 ? rows / 32 : 1;
                 if (bands > kMaxBands) bands = kMaxBands;
             }
-#define DCMT_PREP(KIND, QOUT, O6, QBAD, GATE) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
+#define DCMT_PREP(KIND, QOUT, O6, QBAD, GATE, QCLR) { using G4 = PreP<KIND, true>; using G0 = PreP<KIND, false>; \
                 if (d_x4) { const int strips = (cols + G4::VW - 1) / G4::VW; \
                     hipLaunchKernelGGL((k_pre_p<KIND, true, false, false, QOUT>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, O6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev, QCLR); } \
                 else { const int strips = (cols + G0::VW - 1) / G0::VW; \
                     if (src16) hipLaunchKernelGGL((k_pre_p<KIND, false, true, false, QOUT>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src16, O6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, in_scale, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev, QCLR); \
                     else if (cf) { if constexpr (!QOUT) hipLaunchKernelGGL((k_pre_p<KIND, false, false, true>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, O6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } \
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, cf, tc, cnt, QBAD, GATE, ctx->q16_seen_dev, QCLR); } \
                     else hipLaunchKernelGGL((k_pre_p<KIND, false, false, false, QOUT>), wave_grid(strips * bands, nb, xm), dim3(256), 0, ps, (const void*)src, O6, \
-                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev); } }
+                                       rows, cols, strips, bands, nb, xm, p->max_depth, p->valid_thresh, 1.0f, (const float*)nullptr, tc, cnt, QBAD, GATE, ctx->q16_seen_dev, QCLR); } }
             // 16-bit X6 (k_pre_p<Q16OUT> -> k_fp_q): the whole chain in table mode, two columns per lane, the reference's constants, no
             // normalisation in front (normalised depths are no multiples of 1/256)
             // in place (or overlapping) f32 calls never take the 16-bit attempt: k_fp_q writes dst BEFORE the gated f32 rerun would read src again
@@ -330,10 +335,13 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             if (q16) { const int erc = ensure_x6q(ctx); if (erc != DCMT_OK) return erc; }
             float* x6q = reinterpret_cast<float*>(ctx->x6q + f0 * fe);
             if (q16) {
-                DCMT_HIP(ctx, hipMemsetAsync(ctx->q16_bad, 0, sizeof(int), ps));
-                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, true, x6q, ctx->q16_bad, (const int*)nullptr) else DCMT_PREP(K0_DIAMOND, true, x6q, ctx->q16_bad, (const int*)nullptr)
+                // this attempt's flag (cleared by the previous attempt's kernel, or by dcmt_create) and the next one's, which this attempt's kernel clears
+                qbad = ctx->q16_bad + ctx->q16_attempts % kQ16Flags;
+                int* qnext = ctx->q16_bad + (ctx->q16_attempts + 1) % kQ16Flags;
+                ++ctx->q16_attempts;
+                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, true, x6q, qbad, (const int*)nullptr, qnext) else DCMT_PREP(K0_DIAMOND, true, x6q, qbad, (const int*)nullptr, qnext)
             } else if (pair) {
-                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)nullptr) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)nullptr)
+                if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)nullptr, (int*)nullptr) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)nullptr, (int*)nullptr)
             } else {
                 if (k0kind == K0_AS_COMPILED) { if (wide) DCMT_PRE(K0_AS_COMPILED, true) else DCMT_PRE(K0_AS_COMPILED, false) }
                 else { if (wide) DCMT_PRE(K0_DIAMOND, true) else DCMT_PRE(K0_DIAMOND, false) }
@@ -381,10 +389,10 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     float* o6 = x6;
                     const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr; const float* cf = nullptr; const hipStream_t ps = st;
                     const float* src = (d_x4 ? d_x4 : d_src) + f0 * fe;
-                    if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)ctx->q16_bad) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)ctx->q16_bad)
-                    if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
-                    else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
-                    else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)ctx->q16_bad);
+                    if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)qbad, (int*)nullptr) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)qbad, (int*)nullptr)
+                    if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad);
+                    else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad);
+                    else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad);
                 }
             }
             else if (fpp) {
@@ -412,7 +420,7 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     if (!any) { if (p->verbose) for (int f = 0; f < batch; ++f) std::printf("0\n"); continue; }
                 }
                 hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, x6, pp0, cnt, rows, cols, fstrips, nb, xm, p->valid_thresh, 0, 1, (const int*)tc, bands,
-                                   q16 ? (const unsigned short*)(ctx->x6q + f0 * fe) : (const unsigned short*)nullptr, (const int*)ctx->q16_bad);
+                                   q16 ? (const unsigned short*)(ctx->x6q + f0 * fe) : (const unsigned short*)nullptr, (const int*)qbad);
                 int apps = 0;
                 const int lrc = fill_loop(ctx, batch, p, st, sync_loop, [&](int i) {
                     hipLaunchKernelGGL(k_fill_s, fgrid, b256, 0, st, (i & 1) ? pp0 : pp1, (i & 1) ? pp1 : pp0, cnt, rows, cols,
@@ -486,7 +494,7 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
         // path runs below applies them while it loads
         if (d_src16) return DCMT_E_UNSUPPORTED;
         const size_t fe = (size_t)rows * cols;
-        DCMT_HIP(ctx, hipMemsetAsync(ctx->norm_stats, 0, sizeof(uint32_t) * 2 * (size_t)batch, st));
+        // (norm_stats is all zero here: dcmt_create cleared it, k_norm_coef clears what it has read)
         hipLaunchKernelGGL(k_minmax, dim3(kMinmaxUnits * batch), dim3(256), 0, st, d_src, ctx->norm_stats, fe, batch,
                            (ctx->xcd_map && batch % 8 == 0) ? 1 : 0);
         hipLaunchKernelGGL(k_norm_coef, dim3((batch + 63) / 64), dim3(64), 0, st, ctx->norm_stats, ctx->norm_coef, batch, p->norm_lo, p->norm_hi);
@@ -515,9 +523,11 @@ int run_chain(dcmt_ctx* ctx, const float* d_src, const int32_t* d_labels, int n_
                 DCMT_HIP(ctx, hipMalloc((void**)&ctx->bb_min, sizeof(int) * need));
                 DCMT_HIP(ctx, hipMalloc((void**)&ctx->bb_max, sizeof(int) * need));
                 ctx->bb_ints = need;
+                // "no box" everywhere, once: the label stage's waves put every entry they have read back into this state (a fill in front
+                // of every call is two dependent operations with a bubble behind the previous call's last kernel each)
+                DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_min, 0x7f, sizeof(int) * need, st));
+                DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_max, 0xff, sizeof(int) * need, st));
             }
-            DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_min, 0x7f, sizeof(int) * need, st));
-            DCMT_HIP(ctx, hipMemsetAsync(ctx->bb_max, 0xff, sizeof(int) * need, st));
             float* x4 = stop == DCMT_STAGE_CLOSE5 ? d_dst : ctx->pp[0];       // (dead before the redo chain writes pp[0]; x5 shares pp[1])
             const dim3 bg((cols + 63) / 64, (rows + kBboxRows - 1) / kBboxRows, batch);
             const size_t table = sizeof(int) * 4 * (size_t)n_labels;
@@ -803,7 +813,8 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     if (hipMalloc((void**)&ctx->pp[1], plane) != hipSuccess) return fail(DCMT_E_NOMEM);
     ctx->x5 = ctx->pp[1];
     if (hipMalloc((void**)&ctx->counters, sizeof(int) * (size_t)kCntStride * max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
-    if (hipMalloc((void**)&ctx->q16_bad, 256) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMalloc((void**)&ctx->q16_bad, sizeof(int) * kQ16Flags) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMemset(ctx->q16_bad, 0, sizeof(int) * kQ16Flags) != hipSuccess) return fail(DCMT_E_HIP);
     if (hipHostMalloc((void**)&ctx->q16_seen, 64, hipHostMallocMapped) != hipSuccess) return fail(DCMT_E_NOMEM);
     *ctx->q16_seen = 0;
     if (hipHostGetDevicePointer((void**)&ctx->q16_seen_dev, ctx->q16_seen, 0) != hipSuccess) return fail(DCMT_E_HIP);
@@ -812,6 +823,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     const size_t tb_slots = ctx->bands > 0 ? (size_t)max_batch * kMaxBands : std::min<size_t>((size_t)max_batch * kMaxBands, (size_t)max_batch + 2560);
     if (hipMalloc((void**)&ctx->tb, sizeof(int) * 2 * (size_t)max_cols * tb_slots) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipMalloc((void**)&ctx->norm_stats, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
+    if (hipMemset(ctx->norm_stats, 0, sizeof(uint32_t) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_HIP);
     if (hipMalloc((void**)&ctx->norm_coef, sizeof(float) * 2 * (size_t)max_batch) != hipSuccess) return fail(DCMT_E_NOMEM);
     if (hipHostMalloc((void**)&ctx->h_counters, sizeof(int) * (size_t)kCntStride * max_batch, hipHostMallocDefault) != hipSuccess)
         return fail(DCMT_E_NOMEM);

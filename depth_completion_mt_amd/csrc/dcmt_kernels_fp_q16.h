@@ -73,20 +73,26 @@ __device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { 
 // shifts with 0 in the lane without a source (unsigned codes: 0 is the neutral element of max)
 __device__ __forceinline__ unsigned u_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); }
 __device__ __forceinline__ unsigned u_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true); }
-__device__ __forceinline__ unsigned u_row_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned u_row_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned u_row_ror8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }
+// (bound_ctrl: a lane without a source reads 0 -- what `old = 0` gave, without the v_mov that sets it up)
+__device__ __forceinline__ unsigned u_row_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned u_row_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned u_row_ror8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true); }
 __device__ __forceinline__ void u_row_scans4(unsigned a, unsigned b, unsigned& pa, unsigned& sa, unsigned& pb, unsigned& sb)
 {
-    pa = a; sa = a; pb = b; sb = b;
+    // the first step writes the four scans from a and b themselves (bound_ctrl: max(0, x) = x in a lane without a source): no copies
 #define DCMT_U4(N) "v_max_u32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
                    "v_max_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t" \
                    "v_max_u32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
                    "v_max_u32_dpp %3, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"
     // (b's scans are only looked at in lanes 0..7 (prefix) and 56..63 (suffix): eight lanes each, three steps)
-    asm("s_nop 1\n\t" DCMT_U4(1) DCMT_U4(2) DCMT_U4(4)
+    asm("s_nop 1\n\t"
+        "v_max_u32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_max_u32_dpp %1, %4, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_max_u32_dpp %2, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_max_u32_dpp %3, %5, %5 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        DCMT_U4(2) DCMT_U4(4)
         "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_u32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(pa), "+v"(sa), "+v"(pb), "+v"(sb));
+        "v_max_u32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t" : "=&v"(pa), "=&v"(sa), "=&v"(pb), "=&v"(sb) : "v"(a), "v"(b));
 #undef DCMT_U4
 }
 

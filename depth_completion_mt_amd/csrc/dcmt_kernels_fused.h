@@ -466,6 +466,7 @@ void k_pre_s(const void* __restrict__ src_, float* __restrict__ x6, int rows, in
 // LDS_TABLE: the workgroup (64 columns x kBboxRows rows) first reduces into a per-label table in LDS (ds_min /
 // ds_max, no global traffic) and then issues global atomics only for the handful of labels it touched;
 // without it (label tables too big for LDS) every run start / end goes to global memory directly.
+constexpr int kBboxNone = 0x7f7f7f7f;        // bb_min entry of a label without pixels (what a memset with 0x7f leaves; bb_max: -1)
 constexpr int kBboxRows = 128;               // rows per workgroup (32 per wave, in groups of 8): the table init / flush is paid once per 128 rows
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(256)
@@ -614,7 +615,7 @@ __device__ __forceinline__ void label_pipeline(const FrameBuf& sb, const FrameBu
 template <int K0KIND, bool NORM, bool PAIRS>
 __global__ __launch_bounds__(256)
 void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels,
-                     const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
+                     int* __restrict__ bb_min, int* __restrict__ bb_max, float* __restrict__ x4,
                      int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
 {
     constexpr int HL = K0KIND == K0_AS_COMPILED ? 4 : 6, HR = 6, VW = 64 - HL - HR, H = 6;
@@ -629,6 +630,14 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
     if (PAIRS && Lb < n_labels) { y0b = bb_min[(bo + Lb) * 2]; x0b = bb_min[(bo + Lb) * 2 + 1]; y1b = bb_max[(bo + Lb) * 2]; x1b = bb_max[(bo + Lb) * 2 + 1]; }
     const bool ea = y1a >= 0, eb = y1b >= 0;     // a label may own no pixel
     if (!ea && !eb) return;
+    // every label's box is read by exactly this one wave: at its end it leaves the tables as k_label_bbox expects to find them (no box: what an
+    // empty label's entries still hold), so that no memset has to run in the stream in front of the next call
+    auto reset_boxes = [&]() {
+        if (lane == 0) {
+            bb_min[(bo + La) * 2] = kBboxNone; bb_min[(bo + La) * 2 + 1] = kBboxNone; bb_max[(bo + La) * 2] = -1; bb_max[(bo + La) * 2 + 1] = -1;
+            if (PAIRS && Lb < n_labels) { bb_min[(bo + Lb) * 2] = kBboxNone; bb_min[(bo + Lb) * 2 + 1] = kBboxNone; bb_max[(bo + Lb) * 2] = -1; bb_max[(bo + Lb) * 2 + 1] = -1; }
+        }
+    };
     const size_t fo = (size_t)f * rows * cols, fe = (size_t)rows * cols;
     float na = 1.0f, nb = 0.0f;                    // N1 normalisation
     if constexpr (NORM) { na = coef[2 * f]; nb = coef[2 * f + 1]; }
@@ -647,6 +656,7 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
             const int ha = y1a - y0a, hb = y1b - y0b;
             label_pipeline<K0KIND, NORM, int>(sb, lb, ob, second ? Lb : La, second ? y0b : y0a, second ? y1b : y1a, gx, outlane,
                                               (ha > hb ? ha : hb) + 1 + 2 * H, rows, cols, max_depth, thr, na, nb);
+            reset_boxes();
             return;
         }
     }
@@ -659,6 +669,7 @@ void k_label_stage_s(const float* __restrict__ src, const int32_t* __restrict__ 
             label_pipeline<K0KIND, NORM, int>(sb, lb, ob, L, y0, y1, gx, outlane, y1 - y0 + 1 + 2 * H, rows, cols, max_depth, thr, na, nb);
         }
     }
+    reset_boxes();
 }
 
 // ---------------------------------------------------------------------------------

@@ -81,6 +81,7 @@ constexpr int kMaxBands = 8;                 // row bands per strip (table slots
 // reruns the f32 kernels, gated on that flag).  Table mode only.
 // gate: a launch that only runs if *gate != 0 (the f32 rerun behind a Q16 attempt); nullptr = always.
 // q16_seen: a word of mapped host memory set together with the flag, so that the host can stop attempting on data that is no grid.
+// q16_clear: nullptr, or the flag the next attempt will use (cleared by this launch's first thread).
 
 #ifndef DCMT_PRE_WAVES
 #define DCMT_PRE_WAVES 0
@@ -92,12 +93,16 @@ __attribute__((amdgpu_waves_per_eu(DCMT_PRE_WAVES, DCMT_PRE_WAVES)))
 #endif
 void k_pre_p(const void* __restrict__ src_, float* __restrict__ x6, int rows, int cols, int strips, int bands,
              int batch, int xcd_map, float max_depth, float thr, float in_scale, const float* __restrict__ coef,
-             int* __restrict__ tb, int* __restrict__ counters, int* __restrict__ q16_bad, const int* __restrict__ gate, int* __restrict__ q16_seen)
+             int* __restrict__ tb, int* __restrict__ counters, int* __restrict__ q16_bad, const int* __restrict__ gate, int* __restrict__ q16_seen,
+             int* __restrict__ q16_clear)
 {
     static_assert(!(U16 && START4), "the uint16 ingest is the first kernel of the path");
     static_assert(!(NORM && (U16 || START4)), "normalisation applies to raw f32 frames");
     static_assert(!(NORM && Q16OUT), "normalised frames are not multiples of 1/256");
     if (gate && *gate == 0) return;
+    // the flag of the NEXT 16-bit attempt (a ring of flags, dcmt.hip): cleared here, a whole call ahead of its use, instead of by a
+    // memset in the stream in front of every call (a fill is a dependent operation with a 30-70 us bubble behind the previous kernel)
+    if (q16_clear && blockIdx.x == 0 && threadIdx.x == 0) *q16_clear = 0;
     const float* src = static_cast<const float*>(src_);
     using G = PreP<K0KIND, START4>;
     constexpr int ROFF = START4 ? 6 : 0;         // image row of stream row s is s - ROFF
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(DCMT_LABEL_WAVES, DCMT_LABEL_WAVES)))
 #endif
 void k_label_stage_p(const float* __restrict__ src, const int32_t* __restrict__ labels, int n_labels, int G,
-                     const int* __restrict__ bb_min, const int* __restrict__ bb_max, float* __restrict__ x4,
+                     int* __restrict__ bb_min, int* __restrict__ bb_max, float* __restrict__ x4,
                      int rows, int cols, float max_depth, float thr, const float* __restrict__ coef)
 {
     constexpr int HL = K0KIND == K0_AS_COMPILED ? 4 : 6, HR = 6, H = 6;
@@ -569,6 +574,13 @@ void k_label_stage_p(const float* __restrict__ src, const int32_t* __restrict__ 
         const bool interior = warm && xlo >= 0 && xhi < cols && ymax + nsteps + 7 + DCMT_LABEL_PFD < rows;   // (the step loop runs in eights, the loads DCMT_LABEL_PFD rows ahead)
         if (interior) label_pipeline_p<K0KIND, NORM, true>(sb, lb, ob, L, y0, gx, ox0, ox1, true, nsteps, rows, cols, max_depth, thr, na, nb);
         else label_pipeline_p<K0KIND, NORM, false>(sb, lb, ob, L, y0, gx, ox0, ox1, warm, nsteps, rows, cols, max_depth, thr, na, nb);
+    }
+    // every label's box is read by exactly this one wave: it leaves the tables as k_label_bbox expects to find them (no box), so that no
+    // memset has to run in the stream in front of the next call
+    if (lane < nl) {
+        int2* mn = reinterpret_cast<int2*>(bb_min + (bo + first + lane) * 2);
+        int2* mx = reinterpret_cast<int2*>(bb_max + (bo + first + lane) * 2);
+        *mn = make_int2(kBboxNone, kBboxNone); *mx = make_int2(-1, -1);
     }
 }
 

@@ -105,7 +105,8 @@ void k_minmax(const float* __restrict__ src, uint32_t* __restrict__ stats, size_
     }
 }
 
-__global__ void k_norm_coef(const uint32_t* __restrict__ stats, float* __restrict__ coef, int batch, float lo, float hi)
+// (leaves the frame's two keys zeroed for the next call: no memset in the stream in front of k_minmax)
+__global__ void k_norm_coef(uint32_t* __restrict__ stats, float* __restrict__ coef, int batch, float lo, float hi)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= batch) return;
@@ -116,6 +117,7 @@ __global__ void k_norm_coef(const uint32_t* __restrict__ stats, float* __restric
     const double shift = (double)(float)dmin - (double)(float)(smin * scale);
     coef[2 * f] = (float)scale;
     coef[2 * f + 1] = (float)shift;
+    stats[2 * f] = 0u; stats[2 * f + 1] = 0u;
 }
 
 // the normalised frames themselves (stop_after = DCMT_STAGE_NORMALIZE)
