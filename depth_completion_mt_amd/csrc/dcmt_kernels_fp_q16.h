@@ -19,8 +19,10 @@
 // neighbour moves per row for two columns (k_fp_s: 38.5 per column with v_med3_f32).  The three-input networks of
 // median_shared_nets3.h are half med3 and gain nothing here: a med3 emulated from min3 + max3 + two XORs (or two v_med3_f16 on the
 // halves) costs what the exchange it replaces costs.
-// The median is converted back (code -> f32 is exact: one v_cvt and one fused multiply-add) and the Gaussian, the masked select
-// and the final invert are the f32 code of k_fp_p (PostPipeP::after_median), so the output is bit-identical to k_fp_s's.
+// Behind the median: where the redo chain follows (FILLED), Gaussian and final invert run on the codes as integer-valued floats --
+// exact arithmetic, nothing rounds in the oracle's sequence either (PostPipeP::after_median_codes has the argument); otherwise the
+// median is converted back (code -> f32 is exact: one v_cvt and one fused multiply-add) and the Gaussian, the masked select and the
+// final invert are the f32 code of k_fp_p (PostPipeP::after_median).  Either way the output is bit-identical to k_fp_s's.
 //
 // Fill: the vertical 31-maximum runs packed; the horizontal one, on rows that have a hole, unpacks the two halves and is k_fp_p's
 // scheme on unsigned integers (0 is the neutral element; register B holds the 30 halo columns unpacked, one per lane), with the two
