@@ -17,6 +17,9 @@
  * function returns DCMT_OK (0) or a negative dcmt_status.  A dcmt_ctx is bound to one
  * GPU and owns all scratch memory; it must not be used from two threads at once (one ctx
  * per GPU per host thread -- frames are independent, so multi-GPU is one ctx per device).
+ * Successive *_dev calls on one ctx must be ordered on the device too: the same stream, or streams the caller has ordered with
+ * events (a call's kernels use the scratch memory -- and clear flags -- the next call's kernels rely on).  Work that should overlap
+ * goes to two contexts.
  *
  * Devices and threads: every entry point that takes a ctx makes ctx's device current for the
  * duration of the call and restores the calling thread's current device before it returns, so
