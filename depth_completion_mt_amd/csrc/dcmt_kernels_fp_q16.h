@@ -100,10 +100,12 @@ __device__ __forceinline__ void u_row_scans4(unsigned a, unsigned b, unsigned& p
 
 __device__ __forceinline__ void u_row_scans2(unsigned a, unsigned& pa, unsigned& sa)
 {
-    pa = a; sa = a;
 #define DCMT_U2(N) "v_max_u32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t" \
                    "v_max_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"
-    asm("s_nop 1\n\t" DCMT_U2(1) "s_nop 0\n\t" DCMT_U2(2) "s_nop 0\n\t" DCMT_U2(4) "s_nop 0\n\t" DCMT_U2(8) : "+v"(pa), "+v"(sa));
+    asm("s_nop 1\n\t"
+        "v_max_u32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_max_u32_dpp %1, %2, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t" DCMT_U2(2) "s_nop 0\n\t" DCMT_U2(4) "s_nop 0\n\t" DCMT_U2(8) : "=&v"(pa), "=&v"(sa) : "v"(a));
 #undef DCMT_U2
 }
 
@@ -341,16 +343,18 @@ void k_fp_q(const void* __restrict__ x6_, float* __restrict__ dst, int* __restri
         const unsigned w31a = hmax2(w18a, w18a_old);
         unsigned w31b = 0;
         if constexpr (BREG) {
-            const unsigned w2b = umax2(xb, vpb);
+            // (one code per lane in the low half, 0 above it: the packed f16 forms order these words too, and their three-input one is
+            // formed reliably -- of two chained v_max_u32 the compiler fuses only one)
+            const unsigned w2b = hmax2(xb, vpb);
             vpb = xb;
             W2B[p] = w2b;
-            const unsigned w6b = umax2(umax2(w2b, W2B[(p + 14) & 15]), W2B[(p + 12) & 15]);
+            const unsigned w6b = hmax3(w2b, W2B[(p + 14) & 15], W2B[(p + 12) & 15]);
             W6B[p] = w6b;
-            const unsigned w18b = umax2(umax2(w6b, W6B[(p + 10) & 15]), W6B[(p + 4) & 15]);
+            const unsigned w18b = hmax3(w6b, W6B[(p + 10) & 15], W6B[(p + 4) & 15]);
             const unsigned w18b_old = nxt_b;
             nxt_b = dl_b[(p + 4) & 15][lb];
             dl_b[p][lb] = w18b;
-            w31b = umax2(w18b, w18b_old);
+            w31b = hmax2(w18b, w18b_old);
         }
         const unsigned long long vme = __builtin_amdgcn_ballot_w64((v << 16) <= Q16::HOLE_MAX_HI), vmo = __builtin_amdgcn_ballot_w64(v <= Q16::HOLE_MAX_HI);
         if ((vme | vmo) != 0ull) {
