@@ -62,6 +62,7 @@ struct dcmt_ctx {
     int top_table = 1;                // k_pre leaves the extension zones of X6 unwritten, k_fp_s clamps its rows and starts below the top one; env DCMT_TOP_TABLE=0 disables
     int pair = 1;                     // two columns per lane in H2..H6 (k_pre_p) where the width is even; env DCMT_PAIR=0 keeps k_pre_s
     int bands = 0;                    // row bands per strip in k_pre_p (0 = by batch size); env DCMT_BANDS
+    int fbands = 0;                   // row bands per strip in k_fp_s (0 = by batch size); env DCMT_FBANDS
     int fp_pair = 0;                  // env DCMT_FP_PAIR=1: two columns per lane in H7..H11 (k_fp_p: 8 % fewer VALU instructions, but its ~200 VGPRs leave 2 waves per SIMD and it is slower)
     int fp_q16 = 1;                   // X6 as 16-bit codes + k_fp_q wherever the frames allow it (multiples of 1/256 m: checked on the device, the f32
                                       // kernels rerun behind a raised flag); env DCMT_FP_Q16=0 disables
@@ -361,7 +362,17 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
             const int pstrips = (cols + PostS::VW - 1) / PostS::VW;
             const dim3 pg(((pstrips + 3) / 4) * nb), b256(256);
             // k_fp_s deals (frame, strip) pairs to waves in one flat sequence (per XCD with the XCD map): no half-empty workgroups
-            const dim3 fpg = wave_grid(pstrips, nb, xm);
+            // row bands for k_fp_s: a batch whose strips are fewer than two waves per SIMD runs every strip as fb_s bands, about one
+            // round of three waves per SIMD in all (a band pays 19 + 19 rows of halo and 19 steps of pipeline: only worth it while the
+            // GPU is not full -- from ~100 frames of 1216 columns on there is one band)
+            int fb_s = 1;
+            if (tc) {
+                const long long w1 = (long long)nb * pstrips;
+                fb_s = ctx->fbands > 0 ? ctx->fbands : (w1 >= 2048 ? 1 : (int)((3072 + w1 / 2) / w1));
+                if (fb_s > rows / 32) fb_s = rows / 32 > 0 ? rows / 32 : 1;
+                if (fb_s < 1) fb_s = 1;
+            }
+            const dim3 fpg = wave_grid(pstrips * fb_s, nb, xm);
             // two columns per lane (k_fp_p) wherever a lane's 8-byte stores are aligned: even width, 8-byte aligned frames
             const bool fpp = ctx->fp_pair && cols % 2 == 0 && cols >= 8 && ((uintptr_t)dst % 8 == 0);
             // frames this kernel leaves with holes are recomputed by the redo chain below whenever that chain is enqueued (always on the host
@@ -390,9 +401,9 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                     const uint16_t* src16 = d_src16 ? d_src16 + f0 * fe : nullptr; const float* cf = nullptr; const hipStream_t ps = st;
                     const float* src = (d_x4 ? d_x4 : d_src) + f0 * fe;
                     if (k0kind == K0_AS_COMPILED) DCMT_PREP(K0_AS_COMPILED, false, o6, (int*)nullptr, (const int*)qbad, (int*)nullptr) else DCMT_PREP(K0_DIAMOND, false, o6, (int*)nullptr, (const int*)qbad, (int*)nullptr)
-                    if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad);
-                    else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad);
-                    else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad);
+                    if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad, fb_s);
+                    else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad, fb_s);
+                    else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)qbad, fb_s);
                 }
             }
             else if (fpp) {
@@ -401,14 +412,14 @@ int run_chain_fused(dcmt_ctx* ctx, int k0kind, const float* d_src, float* d_dst,
                 if (bl) hipLaunchKernelGGL((k_fp_p<true>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
                 else    hipLaunchKernelGGL((k_fp_p<false>), qg, qb, 0, st, x6, dst, cnt, rows, cols, qstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands);
             }
-            else if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
-            else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
-            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr);
+            else if (filled) hipLaunchKernelGGL((k_fp_s<true, true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr, fb_s);
+            else if (bl) hipLaunchKernelGGL((k_fp_s<true>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr, fb_s);
+            else    hipLaunchKernelGGL((k_fp_s<false>), fpg, b256, 0, st, x6, dst, cnt, rows, cols, pstrips, nb, xm, p->max_depth, p->valid_thresh, (const int*)tc, bands, (const int*)nullptr, fb_s);
 #undef DCMT_PREP
             DCMT_HIP(ctx, hipGetLastError());
             stamp(3);
             { const size_t n_ = std::strlen(ctx->last_path);
-              std::snprintf(ctx->last_path + n_, sizeof ctx->last_path - n_, " + %s", q16 ? (ctx->fp_h && ctx->q16_breg && (filled || !bl) ? "k_fp_h" : "k_fp_q") : fpp ? "k_fp_p" : "k_fp_s"); }
+              std::snprintf(ctx->last_path + n_, sizeof ctx->last_path - n_, " + %s", q16 ? (ctx->fp_h && ctx->q16_breg && (filled || !bl) ? "k_fp_h" : "k_fp_q") : fpp ? "k_fp_p" : (fb_s > 1 ? "k_fp_s (row bands)" : "k_fp_s")); }
             ctx->last_has_loop = 1;
             const int n_redo = sync_loop ? p->max_fill_iters : (p->spec_fill_iters < p->max_fill_iters ? p->spec_fill_iters : p->max_fill_iters);
             if (n_redo > 0) {
@@ -799,6 +810,7 @@ int dcmt_create(int device, int max_rows, int max_cols, int max_batch, dcmt_ctx*
     { const char* e = std::getenv("DCMT_TOP_TABLE"); if (e) ctx->top_table = std::atoi(e); }
     { const char* e = std::getenv("DCMT_PAIR"); if (e) ctx->pair = std::atoi(e); }
     { const char* e = std::getenv("DCMT_BANDS"); if (e) ctx->bands = std::atoi(e); }
+    { const char* e = std::getenv("DCMT_FBANDS"); if (e) ctx->fbands = std::atoi(e); }
     { const char* e = std::getenv("DCMT_MIN_FUSED_BATCH"); if (e) ctx->min_fused_batch = std::atoi(e); }
     { const char* e = std::getenv("DCMT_LABEL_PAIRS"); if (e) ctx->label_pairs = std::atoi(e); }
     { const char* e = std::getenv("DCMT_LABEL_GROUP"); if (e) ctx->label_group = std::atoi(e); }

@@ -718,12 +718,14 @@ struct PostPipe {
     FrameBuf of;             // output frame
     unsigned ob;             // byte offset of this lane's (clamped) column
     int rows, cols, gx, rl;
+    int so0, so1;            // output rows [so0, so1) are stored (all of them, unless the wave is one row band of its strip: k_fp_s)
     bool outlane, edge_strip;
     float max_depth, thr;
 
     __device__ __forceinline__ void init(float* out_frame, int rows_, int cols_, int gx0, int lane, float max_depth_, float thr_)
     {
         of.init(out_frame, (size_t)rows_ * cols_); rows = rows_; cols = cols_; max_depth = max_depth_; thr = thr_;
+        so0 = 0; so1 = rows_;
         gx = gx0 + lane;
         ob = 4u * (unsigned)min(max(gx, 0), cols - 1);
         outlane = gx >= 0 && gx < cols && lane >= PostS::H && lane < 64 - PostS::H;
@@ -762,7 +764,7 @@ struct PostPipe {
         }
         // ---- vertical pass + select + invert for output row o = j - 2 = u - 6
         const int o = u - 6;
-        if ((unsigned)o < (unsigned)rows) {
+        if ((unsigned)(o - so0) < (unsigned)(so1 - so0)) {
             // slots: row o -> (PP+2)&7, o+1 -> PP+3, o+2 -> PP+4, o-1 -> PP+1, o-2 -> PP
             const float mo = MR[(PP + 2) & 7];
             // the rest of the row, given the four vertical neighbours of the horizontal pass
@@ -989,6 +991,7 @@ void k_fill_s(const float* __restrict__ in, float* __restrict__ out, int* __rest
 // hole is filled by H7).  The kernel counts the holes it leaves per frame (cnt[1]); frames with
 // cnt[1] > 0 are recomputed afterwards by k_fill_s / k_post_s (their only_if_holes modes).
 // ---------------------------------------------------------------------------------
+constexpr int kBandHalo = 19;        // rows of X6 an output row needs above and below it: 15 (H7) + 2 (median) + 2 (Gaussian)
 struct FpS {
     static constexpr int LAG = 29;               // post step u = t - LAG: it takes X7 row u - 2 = t - 31, which the fill front end returns in the same step
 };
@@ -997,7 +1000,7 @@ template <bool BLUR, bool FILLED = false>
 __global__ __launch_bounds__(256)
 void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restrict__ counters,
             int rows_all, int cols, int strips, int batch, int xcd_map, float max_depth, float thr, const int* __restrict__ tb,
-            int tbands, const int* __restrict__ gate)
+            int tbands, const int* __restrict__ gate, int fbands)
 {
     if (gate && *gate == 0) return;          // the f32 rerun behind a 16-bit attempt (k_fp_q): only if that attempt raised its flag
     // per wave, three 15-step delay lines: centre values, A's 16-row maxima (64 lanes each), B's 16-row
@@ -1005,8 +1008,9 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
     __shared__ float s_delay[4][16 * (64 + 64 + 32)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int f, strip;
-    if (!wave_strip(blockIdx.x, wave, strips, batch, xcd_map, f, strip)) return;
+    int f, unit;
+    if (!wave_strip(blockIdx.x, wave, strips * fbands, batch, xcd_map, f, unit)) return;
+    const int strip = unit % strips, band = unit / strips;           // fbands > 1: the strip in row bands, one wave each (small batches)
     int* cnt = frame_counters(counters, f);
     const size_t fo = (size_t)f * rows_all * cols;
     const int gx0 = strip * PostS::VW - PostS::H;
@@ -1030,14 +1034,36 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         table_rows(tb, f, cols, tbands, rows_all, gxbc, tib, bib);
         V = __builtin_amdgcn_readfirstlane(max(wave_min_i(min(tia, tib)) - 8, 0));   // wave-uniform: keep the row arithmetic scalar
     }
-    const int rows = rows_all - V;                                   // rows of the frame as this wave sees it (>= 9)
+    // ---- row bands (fbands > 1: a batch too small to fill the GPU with one wave per strip).  The rows V .. rows_all-1 in fbands
+    // equal parts; a band [b0, b1) streams the rows b0 - 19 .. b1 + 18 (an output row needs X6 within 15 + 2 + 2 rows), treats that
+    // range as its frame -- what the border rules make of its first and last 19 rows is never stored or counted -- and stores
+    // only its own rows.  Band 0 keeps the frame's real top (and the rows above V), the last band its real bottom.
+    int so0 = 0, E = rows_all;
+    const int V_top = V;
+    if (fbands > 1) {
+        const int span = rows_all - V_top;
+        const int b0 = V_top + (int)((long long)span * band / fbands), b1 = V_top + (int)((long long)span * (band + 1) / fbands);
+        if (band > 0) V = max(V_top, b0 - kBandHalo);
+        if (band < fbands - 1) E = min(rows_all, b1 + kBandHalo);
+        so0 = b0 - V;
+        E = max(E, V + 9);
+        // (so1 below; a band of a very short range may be empty: nothing stored, nothing counted)
+    }
+    const int rows = E - V;                                          // rows of the frame as this wave sees it (>= 9)
+    int so1 = rows;
+    if (fbands > 1) {
+        const int span = rows_all - V_top;
+        so1 = V_top + (int)((long long)span * (band + 1) / fbands) - V;
+        if (band == fbands - 1) so1 = rows;
+    }
     FrameBuf sf;
     sf.init(x6 + fo, (size_t)rows_all * cols);
     const unsigned rowb = 4u * (unsigned)cols;
     const unsigned sba = 4u * (unsigned)gxac + (unsigned)V * rowb;   // byte offset of (row V, this lane's column)
     const unsigned sbb = 4u * (unsigned)gxbc + (unsigned)V * rowb;
-    const unsigned fla = 4u * (unsigned)gxac + (unsigned)max(tia, V) * rowb, cea = 4u * (unsigned)gxac + (unsigned)max(bia, V) * rowb;
-    const unsigned flb = 4u * (unsigned)gxbc + (unsigned)max(tib, V) * rowb, ceb = 4u * (unsigned)gxbc + (unsigned)max(bib, V) * rowb;
+    // (a row band may start below a column's last valid row: every row it sees of that column is row bi)
+    const unsigned fla = 4u * (unsigned)gxac + (unsigned)min(max(tia, V), bia) * rowb, cea = 4u * (unsigned)gxac + (unsigned)bia * rowb;
+    const unsigned flb = 4u * (unsigned)gxbc + (unsigned)min(max(tib, V), bib) * rowb, ceb = 4u * (unsigned)gxbc + (unsigned)bib * rowb;
     // (lo <= hi: the median of the three is the clamp.  hipcc has no builtin for the integer med3 and does not form it from min(max()).)
     auto clamp3 = [](unsigned a, unsigned lo, unsigned hi) -> unsigned { unsigned r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi)); return r; };
     auto ld_a = [&](int row) -> float { return sf.ld_at(clamp3(sba + (unsigned)row * rowb, fla, cea)); };   // row relative to V, already clamped to [0, rows)
@@ -1054,6 +1080,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
 
     PostPipe<11, BLUR, FILLED> pipe;
     pipe.init(dst + fo + (size_t)V * cols, rows, cols, gx0, lane, max_depth, thr);
+    pipe.so0 = so0; pipe.so1 = so1;
 
     constexpr float NEG = -FLT_MAX;
     // Warm start: with V > 0 the rows above V equal row V (a hole-free row of the constant zone), so the first 16 steps -- which
@@ -1099,7 +1126,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
             const float d = fmax3(pend_m, pend_slo, pend_phi);
             const bool hole = __builtin_amdgcn_inverse_ballot_w64(pend_hm);   // pend_v < thr, LO :140
             x7 = hole ? d : pend_v;
-            if ((unsigned)o < (unsigned)rows) {                     // hole counts on the scalar unit: ballot + s_bcnt1
+            if ((unsigned)(o - so0) < (unsigned)(so1 - so0)) {      // hole counts on the scalar unit: ballot + s_bcnt1 (a band: its own rows)
                 before += __builtin_popcountll(pend_hm & own_mask);
                 after += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x7 < thr) & own_mask);
             }
@@ -1170,7 +1197,7 @@ void k_fp_s(const float* __restrict__ x6, float* __restrict__ dst, int* __restri
         pipe.template step<((p + 3) & 7)>(x7, u);
         if constexpr (p == 3) {
             // u == 6: output row 0 of the shifted frame (image row V) has just been stored; the V rows above it are equal
-            if (t0 == 32 && V > 0) {
+            if (t0 == 32 && V > 0 && band == 0) {
                 FrameBuf top;
                 top.init(dst + fo, (size_t)V * cols);
                 const unsigned tb = pipe.outlane ? pipe.ob : kDropOffset;

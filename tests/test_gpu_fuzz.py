@@ -46,10 +46,12 @@ def _labels(g, rows, cols):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzz_against_oracle(seed):
+def test_fuzz_against_oracle(seed, monkeypatch):
     from oracle import oracle as O
     g = np.random.Generator(np.random.PCG64(1000 + seed))
+    gb = np.random.Generator(np.random.PCG64(7000 + seed))       # row bands of k_fp_s (read by dcmt_create): 0 = by batch size
     for case in range(10):
+        monkeypatch.setenv("DCMT_FBANDS", str(int(gb.integers(0, 7))))
         rows, cols = int(g.integers(8, 180)), int(g.integers(8, 400))
         batch = int(g.choice([1, 2, 13]))
         k0 = ("as_compiled", "diamond")[g.integers(0, 2)]
