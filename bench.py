@@ -174,6 +174,14 @@ def other_configs(torch, local_rank, d_src, d_dst, params, stream, steps):
     out["1"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, batch=1 streamed (one dcmt_complete_f32_dev call per frame, one stream)",
                 "value": 1e3 / ms, "unit": "frames/s", "us_per_frame": ms * 1e3, "kernels": c1.last_path(), "roofline": hbm_roofline(BYTES_PER_FRAME, ms)}
     c1.close()
+    # 8 frames per call: the smallest batches go through the streaming kernels in row bands (from 3 frames on)
+    b8 = min(8, B)
+    c8 = Context(local_rank, ROWS, COLS, b8)
+    ms = timed(torch, lambda: c8.complete_dev(d_src[:b8], d_dst[:b8], params, stream=stream.cuda_stream), 200, stream)
+    out["8_frames_per_call"] = {"workload": f"DC_lidar_only, {COLS}x{ROWS}, {b8} device-resident frames per call, one stream",
+                                "value": b8 * 1e3 / ms, "unit": "frames/s", "us_per_frame": ms * 1e3 / b8, "kernels": c8.last_path(),
+                                "roofline": hbm_roofline(b8 * BYTES_PER_FRAME, ms)}
+    c8.close()
     # [4] at 8 GPUs = 128 frames per GPU per step: that per-GPU workload on this GPU
     b128 = min(128, B)
     c4 = Context(local_rank, ROWS, COLS, b128)

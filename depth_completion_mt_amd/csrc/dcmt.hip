@@ -97,8 +97,9 @@ struct dcmt_ctx {
     size_t slic_center_cap = 0;                 // centres per frame the two buffers above hold
     int label_group = 0;              // LC fast path, two columns per lane: labels side by side per wave (0 = by label size); env DCMT_LABEL_GROUP
     int label_pairs = -1;             // LC fast path: one wave per label pair (1), per label (0), by label size (-1); env DCMT_LABEL_PAIRS
-    int min_fused_batch = 8;          // smaller batches use the staged kernels (measured crossover, tools/batch_sweep.py: 6 frames 49 k staged / 44 k streaming,
-                                      // 8 frames 51 k / 58 k, 12 frames 53 k / 84 k frames/s); env DCMT_MIN_FUSED_BATCH
+    int min_fused_batch = 3;          // smaller batches use the staged kernels (measured crossover with both streaming kernels in row bands,
+                                      // tools/batch_sweep.py: 1 frame 20.6 k staged / 17.1 k streaming, 2 frames 34.7 k / 34.0 k, 3 frames 39.5 k / 50.4 k,
+                                      // 4 frames 42.6 k / 65.7 k, 8 frames 52 k / 124 k frames/s); env DCMT_MIN_FUSED_BATCH
 };
 
 namespace {

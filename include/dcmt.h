@@ -122,7 +122,7 @@ typedef struct {
  * Both paths produce identical bits. */
 #define DCMT_FLAG_FORCE_STAGED 1
 /* Use the fused streaming kernels even for a batch too small to fill the GPU with them (by default
- * batches of fewer than 8 frames take the staged tile kernels, whose many small workgroups have the
+ * batches of fewer than 3 frames take the staged tile kernels, whose many small workgroups have the
  * lower latency for a single frame).  Both paths produce identical bits. */
 #define DCMT_FLAG_FORCE_FUSED 2
 
