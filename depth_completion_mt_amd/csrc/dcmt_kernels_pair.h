@@ -445,9 +445,9 @@ __device__ __forceinline__ void label_pipeline_p(const FrameBuf& sb, const Frame
     };
 #pragma unroll
     for (int q = 0; q < PFD; ++q) fetch(q, rs + q, q);
-    for (int s0 = 0; s0 < nsteps; s0 += 8) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
+    int s0 = 0;
+    auto step = [&](auto P_) __attribute__((always_inline)) {
+            constexpr int p = decltype(P_)::value;
             const int i = rs + (s0 + p);             // image row fed by this step (per lane)
             F2 raw = PF[p];
             const int le = PLe[p], lo = PLo[p];
@@ -492,7 +492,16 @@ __device__ __forceinline__ void label_pipeline_p(const FrameBuf& sb, const Frame
                 ob.st_at((inl && oute && LBe[(p + 2) & 7] == L) ? wo : kDropOffset, e4.e);
                 ob.st_at((inl && outo && LBo[(p + 2) & 7] == L) ? wo + 4u : kDropOffset, e4.o);
             }
-        }
+    };
+    // (a pass is h + 6 steps, ~28: a way out in the middle of the eight-step block saves two of the ~3.5 steps a pass runs past its end)
+    for (; s0 < nsteps; s0 += 8) {
+        static_for<0, 2>(step);
+        if (s0 + 2 >= nsteps) break;
+        static_for<2, 4>(step);
+        if (s0 + 4 >= nsteps) break;
+        static_for<4, 6>(step);
+        if (s0 + 6 >= nsteps) break;
+        static_for<6, 8>(step);
     }
 }
 
